@@ -1,0 +1,209 @@
+"""ctypes binding of libghf_hip.so (the C ABI in include/ghf.h).
+
+There is no CPU or eager-PyTorch fallback behind these functions: if the
+library cannot be loaded the first call raises, loudly.  torch appears here
+only to obtain device pointers and the current HIP stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import threading
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _build
+
+_lock = threading.Lock()
+_lib: Optional[C.CDLL] = None
+
+GHF_FLAG_NO_TAIL = 1
+WLAYOUT_NATURAL = 0
+WLAYOUT_FRAG16 = 1
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every function declared in include/ghf.h
+SIGNATURES = {
+    "ghf_abi_version": (_i32, []),
+    "ghf_last_error": (C.c_char_p, []),
+    "ghf_message_config": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ghf_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "ghf_plan_build": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+                                 _vp, _vp, _vp, _vp]),
+    "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "ghf_message_layer_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32,
+                                     _vp, _vp, _f32, _i64, _i64, _vp, _i32, _vp]),
+    "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
+}
+
+
+def header_symbols() -> List[str]:
+    """Function names declared in include/ghf.h (for the export test)."""
+    with open(os.path.join(_build.INCLUDE, "ghf.h")) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(ghf_[a-z_0-9]+)\s*\(", text)))
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libghf_hip.so (building it first if it is absent and hipcc is here)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            try:
+                _build.build()
+            except Exception as exc:  # noqa: BLE001
+                raise RuntimeError(
+                    f"libghf_hip.so is missing at {path} and could not be built ({exc}). "
+                    "This package has no CPU/PyTorch fallback: run __graft_entry__.build() first.") from exc
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.ghf_abi_version() != 1:
+            raise RuntimeError(f"libghf_hip.so ABI version {lib.ghf_abi_version()} != 1")
+        _lib = lib
+        return lib
+
+
+class GhfError(RuntimeError):
+    pass
+
+
+def _check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().ghf_last_error().decode("utf-8", "replace")
+        if code == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise GhfError(f"{what} failed (code {code}): {msg}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------
+# thin wrappers (tensors in, tensors out; all work enqueued on the current stream)
+# ---------------------------------------------------------------------------
+
+def message_config(d: int) -> Tuple[int, int]:
+    bn, wl = _i32(0), _i32(0)
+    _check(load().ghf_message_config(int(d), C.byref(bn), C.byref(wl)), "ghf_message_config")
+    return bn.value, wl.value
+
+
+def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, block_nodes: int):
+    """Returns (sorted_key u32-as-int32 tensor, sorted_src, seg_off, indeg, status)."""
+    lib = load()
+    ei = _req(edge_index, torch.int64, "edge_index")
+    rel = _req(rel_id, torch.int64, "rel_id")
+    E = ei.size(1)
+    dev = ei.device
+    nb = (N + block_nodes - 1) // block_nodes
+    nseg = N if block_nodes == 1 else nb * R
+    ws_bytes = lib.ghf_plan_workspace_bytes(N, E, R, block_nodes)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    skey = torch.empty(E, dtype=torch.int32, device=dev)      # holds uint32 bit patterns
+    ssrc = torch.empty(E, dtype=torch.int32, device=dev)
+    seg_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    indeg = torch.empty(N, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    _check(lib.ghf_plan_build(_ptr(ei), _ptr(rel), N, E, R, block_nodes, _ptr(ws), ws_bytes, _ptr(skey), _ptr(ssrc),
+                              _ptr(seg_off), _ptr(indeg), _ptr(status), _stream()), "ghf_plan_build")
+    return skey, ssrc, seg_off, indeg, status
+
+
+def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], log_scales: torch.Tensor,
+                  T: int, Hh: int, num_hidden: int, d_in: int, d_out: int, layout: int,
+                  out: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]] = None):
+    """head_params: flat list [head][layer][weight,bias]; returns (W_msg or Wfrag, W_self or None, bias)."""
+    lib = load()
+    x = _req(text_emb, torch.float32, "text_emb")
+    R = x.size(0)
+    dev = x.device
+    keep = [_req(p, torch.float32, "weight-generator parameter") for p in head_params]
+    arr = (_vp * len(keep))(*[p.data_ptr() for p in keep])
+    ls = _req(log_scales, torch.float32, "log_scales")
+    hidden_ws = torch.empty(3 * 2 * R * max(Hh, T, 1), dtype=torch.float32, device=dev)
+    if out is None:
+        if layout == WLAYOUT_FRAG16:
+            W_msg = torch.empty(2 * R * d_in * d_out, dtype=torch.float32, device=dev)
+            W_self = None
+        else:
+            W_msg = torch.empty(R, d_in, d_out, dtype=torch.float32, device=dev)
+            W_self = torch.empty(R, d_in, d_out, dtype=torch.float32, device=dev)
+        bias = torch.empty(R, d_out, dtype=torch.float32, device=dev)
+    else:
+        W_msg, W_self, bias = out
+    _check(lib.ghf_weightgen_fwd(_ptr(x), arr, _ptr(ls), R, T, Hh, num_hidden, d_in, d_out, layout,
+                                 _ptr(hidden_ws), _ptr(W_msg), _ptr(W_self), _ptr(bias), _stream()),
+           "ghf_weightgen_fwd")
+    return W_msg, W_self, bias
+
+
+def input_proj_fwd(x: torch.Tensor, W_in: torch.Tensor, b_in: torch.Tensor, out: Optional[torch.Tensor] = None):
+    lib = load()
+    x = _req(x, torch.float32, "node_features")
+    W = _req(W_in, torch.float32, "input_proj.weight")
+    b = _req(b_in, torch.float32, "input_proj.bias")
+    N, F = x.shape
+    d = W.size(0)
+    if W.size(1) != F:
+        raise ValueError(f"node_features has {F} columns but input_proj expects {W.size(1)}")
+    h0 = torch.empty(N, d, dtype=torch.float32, device=x.device) if out is None else out
+    _check(lib.ghf_input_proj_fwd(_ptr(x), _ptr(W), _ptr(b), N, F, d, _ptr(h0), _stream()), "ghf_input_proj_fwd")
+    return h0
+
+
+def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Optional[torch.Tensor],
+                      bias: torch.Tensor, wlayout: int, ln_gamma: Optional[torch.Tensor],
+                      ln_beta: Optional[torch.Tensor], ln_eps: float, h_out: torch.Tensor,
+                      row0: int = 0, rows: Optional[int] = None, flags: int = 0) -> torch.Tensor:
+    """`plan` is any object with sorted_key, sorted_src, seg_off, indeg, N, E, R, block_nodes."""
+    lib = load()
+    h = _req(h, torch.float32, "h")
+    N, d = h.shape
+    if rows is None:
+        rows = N - row0
+    _check(lib.ghf_message_layer_fwd(_ptr(h), N, d, _ptr(plan.sorted_key), _ptr(plan.sorted_src), _ptr(plan.seg_off),
+                                     _ptr(plan.indeg), plan.E, plan.R, plan.block_nodes, _ptr(W_msg), _ptr(W_self),
+                                     _ptr(bias), wlayout, _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows,
+                                     _ptr(h_out), flags, _stream()), "ghf_message_layer_fwd")
+    return h_out
+
+
+def tail_fwd(agg: torch.Tensor, h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, ln_eps: float,
+             h_out: torch.Tensor, row0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
+    lib = load()
+    N, d = h.shape
+    if rows is None:
+        rows = N - row0
+    _check(lib.ghf_tail_fwd(_ptr(agg), _ptr(h), _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows, d,
+                            _ptr(h_out), _stream()), "ghf_tail_fwd")
+    return h_out

@@ -1,0 +1,98 @@
+// capi.hip — the extern "C" surface declared in include/ghf.h.
+#include "common.h"
+
+#include <string.h>
+
+namespace ghf {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace ghf
+
+using namespace ghf;
+
+extern "C" {
+
+int ghf_abi_version(void) { return GHF_ABI_VERSION; }
+
+const char* ghf_last_error(void) { return err_buf(); }
+
+int ghf_message_config(int d, int* block_nodes, int* wlayout) {
+    if (!block_nodes || !wlayout) return set_err(GHF_EINVAL, "message_config: null output pointer");
+    int bn = 1;
+    if (message_mfma_config(d, &bn)) {
+        *block_nodes = bn;
+        *wlayout = GHF_WLAYOUT_FRAG16;
+    } else {
+        *block_nodes = 1;
+        *wlayout = GHF_WLAYOUT_NATURAL;
+    }
+    return GHF_OK;
+}
+
+size_t ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes) {
+    return plan_workspace_bytes(N, E, R, block_nodes);
+}
+
+int ghf_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, int64_t E, int R, int block_nodes,
+                   void* workspace, size_t workspace_bytes, uint32_t* sorted_key, int32_t* sorted_src,
+                   int32_t* seg_off, int32_t* indeg, int32_t* status, void* stream) {
+    GHF_REQUIRE(edge_index && rel_id && workspace && sorted_key && sorted_src && seg_off && indeg && status,
+                "plan_build: null pointer argument");
+    return launch_plan_build(edge_index, rel_id, N, E, R, block_nodes, workspace, workspace_bytes, sorted_key,
+                             sorted_src, seg_off, indeg, status, (hipStream_t)stream);
+}
+
+int ghf_weightgen_fwd(const float* text_emb, const float* const* head_params, const float* log_scales,
+                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout, float* hidden_ws,
+                      float* W_msg, float* W_self, float* bias, void* stream) {
+    GHF_REQUIRE(text_emb && head_params && log_scales && hidden_ws && W_msg && bias,
+                "weightgen_fwd: null pointer argument");
+    return launch_weightgen(text_emb, head_params, log_scales, R, T, Hh, num_hidden, d_in, d_out, layout,
+                            hidden_ws, W_msg, W_self, bias, (hipStream_t)stream);
+}
+
+int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
+                       float* h0, void* stream) {
+    GHF_REQUIRE(x && W_in && b_in && h0, "input_proj_fwd: null pointer argument");
+    return launch_input_proj(x, W_in, b_in, N, F, d, h0, (hipStream_t)stream);
+}
+
+int ghf_message_layer_fwd(const float* h, int64_t N, int d, const uint32_t* sorted_key, const int32_t* sorted_src,
+                          const int32_t* seg_off, const int32_t* indeg, int64_t E, int R, int block_nodes,
+                          const float* W_msg, const float* W_self, const float* bias, int wlayout,
+                          const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0, int64_t rows,
+                          float* h_out, int flags, void* stream) {
+    GHF_REQUIRE(h && sorted_key && sorted_src && seg_off && indeg && W_msg && bias && h_out,
+                "message_layer_fwd: null pointer argument");
+    GHF_REQUIRE((flags & GHF_FLAG_NO_TAIL) || (ln_gamma && ln_beta), "message_layer_fwd: LayerNorm parameters missing");
+    GHF_REQUIRE(h != h_out, "message_layer_fwd: h_out must not alias h");
+    GHF_REQUIRE(N > 0 && d > 0 && R > 0 && block_nodes > 0, "message_layer_fwd: N, d, R, block_nodes must be positive");
+    GHF_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= N, "message_layer_fwd: row range [%lld,+%lld) outside [0,%lld)",
+                (long long)row0, (long long)rows, (long long)N);
+    GHF_REQUIRE(row0 % block_nodes == 0, "message_layer_fwd: row0 must be a multiple of block_nodes");
+    MsgArgs a{h, N, d, sorted_key, sorted_src, seg_off, indeg, E, R, block_nodes, W_msg, W_self, bias, wlayout,
+              ln_gamma, ln_beta, ln_eps, row0, rows, h_out, flags};
+    if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
+    return launch_message_mfma(a, (hipStream_t)stream);
+}
+
+int ghf_tail_fwd(const float* agg, const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                 int64_t row0, int64_t rows, int d, float* h_out, void* stream) {
+    GHF_REQUIRE(agg && h && ln_gamma && ln_beta && h_out, "tail_fwd: null pointer argument");
+    GHF_REQUIRE(row0 >= 0 && rows >= 0, "tail_fwd: bad row range");
+    return launch_tail(agg, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

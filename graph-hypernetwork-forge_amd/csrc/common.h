@@ -1,0 +1,90 @@
+// common.h — shared helpers for libghf_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ghf.h"
+
+namespace ghf {
+
+// thread-local last-error text behind ghf_last_error()
+char* err_buf();
+int set_err(int code, const char* fmt, ...);
+
+#define GHF_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            return ghf::set_err(GHF_EHIP, "%s failed: %s (%s:%d)", #expr,                \
+                                hipGetErrorString(_e), __FILE__, __LINE__);              \
+    } while (0)
+
+#define GHF_LAUNCH_CHECK() GHF_HIP_CHECK(hipGetLastError())
+
+#define GHF_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) return ghf::set_err(GHF_EINVAL, __VA_ARGS__);                       \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int WAVE = 64;
+constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
+
+// ---- wave / block reductions (64-lane wavefronts) --------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over a block of NWAVES*64 threads; `red` is >= NWAVES floats of LDS.
+// All threads get the result.  Contains two barriers.
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if constexpr (NWAVES == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) t += red[i];
+    return t;
+}
+
+// Launchers (one per translation unit), called from capi.hip.
+int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, int64_t E, int R,
+                      int block_nodes, void* ws, size_t ws_bytes, uint32_t* sorted_key,
+                      int32_t* sorted_src, int32_t* seg_off, int32_t* indeg, int32_t* status,
+                      hipStream_t stream);
+size_t plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes);
+
+int launch_weightgen(const float* text_emb, const float* const* head_params, const float* log_scales,
+                     int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
+                     float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream);
+
+int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
+                      float* h0, hipStream_t stream);
+
+struct MsgArgs {
+    const float* h; int64_t N; int d;
+    const uint32_t* sorted_key; const int32_t* sorted_src; const int32_t* seg_off; const int32_t* indeg;
+    int64_t E; int R; int block_nodes;
+    const float* W_msg; const float* W_self; const float* bias; int wlayout;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    int64_t row0; int64_t rows; float* h_out; int flags;
+};
+int launch_message_generic(const MsgArgs& a, hipStream_t stream);
+int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
+bool message_mfma_config(int d, int* block_nodes);
+
+int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,
+                int64_t row0, int64_t rows, int d, float* h_out, hipStream_t stream);
+
+}  // namespace ghf

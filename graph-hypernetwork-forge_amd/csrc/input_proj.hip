@@ -1,0 +1,108 @@
+// input_proj.hip — h0 = relu(x @ W_in^T + b_in)   (reference models/hypergnn.py:261).
+//
+// x [N,F] and W_in [d,F] are both row-major with the contraction index contiguous, so
+// both MFMA operands load the same way: lane l reads 16 bytes at [row l&15][16j + 4(l>>4)]
+// and uses element s in step s of v_mfma_f32_16x16x4_f32 (a k-permutation shared by A and
+// B; exact fp32 fma chain).  A wave owns IP_MT*16 rows and all d output columns, so each
+// W_in fragment loaded from L1/L2 is reused IP_MT times and x is read from HBM once.
+// Shapes the tile does not cover (F % 16, d % 16, d > 256) take a vector-ALU kernel.
+#include "common.h"
+
+namespace ghf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int IP_MT = 2;       // m-tiles (16 rows each) per wave
+
+template <int NT>  // n-tiles of 16 output columns: d = 16*NT
+__global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, int64_t N, int F,
+                                                              float* __restrict__ h0) {
+    constexpr int D = 16 * NT;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int64_t row_base = ((int64_t)blockIdx.x * 4 + wv) * (16 * IP_MT);
+    if (row_base >= N) return;
+
+    const float* arow[IP_MT];
+#pragma unroll
+    for (int m = 0; m < IP_MT; ++m) {
+        int64_t r = row_base + 16 * m + c16;
+        if (r >= N) r = N - 1;                           // clamp: rows past N are computed but not stored
+        arow[m] = x + (size_t)r * F + 4 * q;
+    }
+    f32x4 acc[IP_MT][NT];
+#pragma unroll
+    for (int m = 0; m < IP_MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float bv = bias[16 * t + c16];         // D column = lane & 15
+            acc[m][t] = (f32x4){bv, bv, bv, bv};
+        }
+    const int NJ = F >> 4;
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 a[IP_MT];
+#pragma unroll
+        for (int m = 0; m < IP_MT; ++m) a[m] = *(const f32x4*)(arow[m] + 16 * j);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 b = *(const f32x4*)(W + (size_t)(16 * t + c16) * F + 16 * j + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < IP_MT; ++m)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m][t], 0, 0, 0);
+        }
+    }
+    // D: lane holds rows 4q + reg, column 16t + c16
+#pragma unroll
+    for (int m = 0; m < IP_MT; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t r = row_base + 16 * m + 4 * q + s;
+            if (r < N) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) h0[(size_t)r * D + 16 * t + c16] = fmaxf(acc[m][t][s], 0.f);
+            }
+        }
+}
+
+// Fallback: one wave per row, lanes stride output columns.
+__global__ __launch_bounds__(256) void input_proj_simple_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, int64_t N, int F, int d,
+                                                                float* __restrict__ h0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const float* __restrict__ xr = x + (size_t)r * F;
+    for (int o = lane; o < d; o += 64) {
+        float s = bias[o];
+        const float* __restrict__ wr = W + (size_t)o * F;
+        for (int k = 0; k < F; ++k) s = fmaf(xr[k], wr[k], s);
+        h0[(size_t)r * d + o] = fmaxf(s, 0.f);
+    }
+}
+
+int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
+                      float* h0, hipStream_t stream) {
+    GHF_REQUIRE(N > 0 && F > 0 && d > 0, "input_proj: N, F, d must be positive");
+    const bool aligned = ((((uintptr_t)x | (uintptr_t)W_in) & 15) == 0);
+    const bool mfma_ok = aligned && (F % 16) == 0 && (d % 16) == 0 && d <= 256;
+    if (mfma_ok) {
+        const int64_t rows_per_block = 4 * 16 * IP_MT;
+        const unsigned grid = (unsigned)cdiv(N, rows_per_block);
+        switch (d / 16) {
+#define GHF_IP_CASE(NT) case NT: input_proj_mfma_kernel<NT><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0); break;
+            GHF_IP_CASE(1) GHF_IP_CASE(2) GHF_IP_CASE(3) GHF_IP_CASE(4) GHF_IP_CASE(5) GHF_IP_CASE(6)
+            GHF_IP_CASE(7) GHF_IP_CASE(8) GHF_IP_CASE(9) GHF_IP_CASE(10) GHF_IP_CASE(11) GHF_IP_CASE(12)
+            GHF_IP_CASE(13) GHF_IP_CASE(14) GHF_IP_CASE(15) GHF_IP_CASE(16)
+#undef GHF_IP_CASE
+        }
+    } else {
+        input_proj_simple_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(x, W_in, b_in, N, F, d, h0);
+    }
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+}  // namespace ghf

@@ -1,0 +1,149 @@
+// message_generic.hip — K2+K3 for any hidden size d (vector ALU), and K3 alone.
+//
+// Replaces models/hypergnn.py:281-296 of the reference without ever forming the
+// per-edge weight copies of :281-283.  Plan geometry: CSR by destination
+// (block_nodes == 1, key = dst*R + rel, seg_off = row offsets), weights in the
+// reference's natural layout.  One workgroup per destination node v:
+//     acc[o] = sum_{e=(u->v)} ( bias[r_e][o] + sum_i h_u[i] W_msg[r_e][i][o] + h_v[i] W_self[r_e][i][o] )
+//     x[o]   = acc[o] / max(indeg_v, 1) + h_v[o];  h'_v = LayerNorm(ReLU(x))
+// Lanes own output columns o (coalesced reads of W[r][i][:]); h_u and h_v sit in LDS.
+// Edges arrive sorted by (dst, rel), so the summation order is fixed: results are
+// bitwise reproducible run to run.
+// This is the correctness-first kernel; the MFMA kernel in message_mfma.hip takes over
+// for the hidden sizes it is built for.
+#include "common.h"
+
+namespace ghf {
+
+constexpr int GEN_MAX_D = 1024;
+constexpr int GEN_TPB = 256;
+constexpr int GEN_MAX_PER_THREAD = GEN_MAX_D / GEN_TPB;
+
+template <int NW>
+__device__ __forceinline__ void tail_store(const float (&x)[GEN_MAX_PER_THREAD], int d, float* red,
+                                           const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                           float* __restrict__ out_row) {
+    // LayerNorm over d values spread as x[c] <-> column threadIdx.x + c*blockDim.x (biased variance)
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+        const int o = threadIdx.x + c * GEN_TPB;
+        if (o < d) s += x[c];
+    }
+    const float mean = block_sum<NW>(s, red) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+        const int o = threadIdx.x + c * GEN_TPB;
+        if (o < d) { const float t = x[c] - mean; v += t * t; }
+    }
+    const float var = block_sum<NW>(v, red + NW) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+        const int o = threadIdx.x + c * GEN_TPB;
+        if (o < d) out_row[o] = (x[c] - mean) * rstd * g[o] + b[o];
+    }
+}
+
+__global__ __launch_bounds__(GEN_TPB) void message_generic_kernel(
+    const float* __restrict__ h, int d, const uint32_t* __restrict__ key, const int32_t* __restrict__ srcs,
+    const int32_t* __restrict__ row_off, const int32_t* __restrict__ indeg, int R,
+    const float* __restrict__ Wm, const float* __restrict__ Ws, const float* __restrict__ bias,
+    const float* __restrict__ g, const float* __restrict__ b, float eps, int64_t row0,
+    float* __restrict__ h_out, int no_tail) {
+    __shared__ float hv[GEN_MAX_D];
+    __shared__ float hu[GEN_MAX_D];
+    __shared__ float red[2 * (GEN_TPB / 64)];
+    const int64_t v = row0 + blockIdx.x;
+    const float* __restrict__ hrow = h + (size_t)v * d;
+    for (int i = threadIdx.x; i < d; i += GEN_TPB) hv[i] = hrow[i];
+
+    float acc[GEN_MAX_PER_THREAD];
+#pragma unroll
+    for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) acc[c] = 0.f;
+
+    const int e0 = row_off[v], e1 = row_off[v + 1];
+    const size_t dd = (size_t)d * d;
+    for (int e = e0; e < e1; ++e) {
+        const int r = (int)(key[e] - (uint32_t)v * (uint32_t)R);
+        const float* __restrict__ urow = h + (size_t)srcs[e] * d;
+        __syncthreads();                                   // previous hu fully consumed; hv visible on first pass
+        for (int i = threadIdx.x; i < d; i += GEN_TPB) hu[i] = urow[i];
+        __syncthreads();
+        const float* __restrict__ wm = Wm + (size_t)r * dd;
+        const float* __restrict__ ws = Ws + (size_t)r * dd;
+#pragma unroll
+        for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+            const int o = threadIdx.x + c * GEN_TPB;
+            if (o < d) {
+                float s = bias[(size_t)r * d + o];
+                for (int i = 0; i < d; ++i) {
+                    s = fmaf(hu[i], wm[(size_t)i * d + o], s);
+                    s = fmaf(hv[i], ws[(size_t)i * d + o], s);
+                }
+                acc[c] += s;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int deg = indeg[v];
+    const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+    float* __restrict__ orow = h_out + (size_t)v * d;
+    if (no_tail) {
+#pragma unroll
+        for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+            const int o = threadIdx.x + c * GEN_TPB;
+            if (o < d) orow[o] = acc[c] * inv;
+        }
+        return;
+    }
+    float x[GEN_MAX_PER_THREAD];
+#pragma unroll
+    for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+        const int o = threadIdx.x + c * GEN_TPB;
+        x[c] = (o < d) ? fmaxf(acc[c] * inv + hv[o], 0.f) : 0.f;
+    }
+    tail_store<GEN_TPB / 64>(x, d, red, g, b, eps, orow);
+}
+
+// K3 alone: h' = LayerNorm(ReLU(agg + h)) on rows [row0, row0+rows)
+__global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__ agg, const float* __restrict__ h,
+                                                       const float* __restrict__ g, const float* __restrict__ b,
+                                                       float eps, int64_t row0, int d, float* __restrict__ h_out) {
+    __shared__ float red[2 * (GEN_TPB / 64)];
+    const int64_t v = row0 + blockIdx.x;
+    float x[GEN_MAX_PER_THREAD];
+#pragma unroll
+    for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
+        const int o = threadIdx.x + c * GEN_TPB;
+        x[c] = (o < d) ? fmaxf(agg[(size_t)v * d + o] + h[(size_t)v * d + o], 0.f) : 0.f;
+    }
+    tail_store<GEN_TPB / 64>(x, d, red, g, b, eps, h_out + (size_t)v * d);
+}
+
+int launch_message_generic(const MsgArgs& a, hipStream_t stream) {
+    GHF_REQUIRE(a.block_nodes == 1, "message(generic): plan must be CSR (block_nodes == 1), got %d", a.block_nodes);
+    GHF_REQUIRE(a.wlayout == GHF_WLAYOUT_NATURAL && a.W_self, "message(generic): needs NATURAL weights");
+    GHF_REQUIRE(a.d >= 1 && a.d <= GEN_MAX_D, "message(generic): d=%d outside [1,%d]", a.d, GEN_MAX_D);
+    GHF_REQUIRE(a.rows < (1ll << 31), "message(generic): too many rows per launch");
+    if (a.rows <= 0) return GHF_OK;
+    message_generic_kernel<<<(unsigned)a.rows, GEN_TPB, 0, stream>>>(
+        a.h, a.d, a.sorted_key, a.sorted_src, a.seg_off, a.indeg, a.R, a.W_msg, a.W_self, a.bias,
+        a.ln_gamma, a.ln_beta, a.ln_eps, a.row0, a.h_out, (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,
+                int64_t row0, int64_t rows, int d, float* h_out, hipStream_t stream) {
+    GHF_REQUIRE(d >= 1 && d <= GEN_MAX_D, "tail: d=%d outside [1,%d]", d, GEN_MAX_D);
+    GHF_REQUIRE(rows < (1ll << 31), "tail: too many rows per launch");
+    if (rows <= 0) return GHF_OK;
+    tail_kernel<<<(unsigned)rows, GEN_TPB, 0, stream>>>(agg, h, g, b, eps, row0, d, h_out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+}  // namespace ghf

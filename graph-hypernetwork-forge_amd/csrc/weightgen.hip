@@ -1,0 +1,216 @@
+// weightgen.hip — K1: relation-batched WeightGenerator forward.
+//
+// Replaces models/weight_generator.py:137-141 of the reference: for each head
+// k in {W_msg, W_self, bias}:  flat_k = Lin_last(ReLU(Lin(...ReLU(Lin_0(x)))))
+// (nn.Linear: y = x W^T + b, W stored [out,in]), out_k = flat_k * exp(log_scale_k).
+//
+//  wg_hidden_kernel : the num_hidden small Linear+ReLU layers, one workgroup per
+//                     (relation, head), activations ping-ponged in LDS.
+//  wg_out_mfma_kernel: the last layer [R,Hl] x [Hl, n_out] as an fp32 MFMA GEMM
+//                     (v_mfma_f32_16x16x4_f32: exact fp32 fma chain), transposed so that the
+//                     output-element index is the MFMA row and the relation the
+//                     MFMA column; the epilogue scales by exp(log_scale) and stores
+//                     either the reference's natural layout or the B-fragment
+//                     layout the message kernel reads (GHF_WLAYOUT_FRAG16).
+//  wg_out_simple_kernel: same contraction on the vector ALU for shapes the MFMA
+//                     tile does not cover (Hl % 16 != 0) and for the tiny bias head.
+#include "common.h"
+
+namespace ghf {
+
+constexpr int WG_MAX_WIDTH = 1024;   // max(T, Hh) supported by the LDS ping-pong buffers
+
+struct HeadPtrs {
+    const float* w[3][8];     // [head][layer] weight
+    const float* b[3][8];     // [head][layer] bias
+};
+
+// grid (R, 3); block 256.  hidden_ws[(head*R + r)*Hl + j], Hl = num_hidden ? Hh : T.
+__global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict__ text_emb, HeadPtrs P,
+                                                        int R, int T, int Hh, int num_hidden,
+                                                        float* __restrict__ hidden_ws) {
+    __shared__ float buf[2][WG_MAX_WIDTH];
+    const int r = blockIdx.x, head = blockIdx.y;
+    for (int k = threadIdx.x; k < T; k += blockDim.x) buf[0][k] = text_emb[(size_t)r * T + k];
+    __syncthreads();
+    int cur = 0, in_dim = T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int li = 0; li < num_hidden; ++li) {
+        const float* __restrict__ W = P.w[head][li];
+        const float* __restrict__ B = P.b[head][li];
+        // one wave per output unit: lanes stride the contraction, then a wave reduction
+        for (int j = wv; j < Hh; j += nw) {
+            float s = 0.f;
+            for (int k = lane; k < in_dim; k += 64) s = fmaf(buf[cur][k], W[(size_t)j * in_dim + k], s);
+            s = wave_sum(s);
+            if (lane == 0) buf[cur ^ 1][j] = fmaxf(s + B[j], 0.f);
+        }
+        __syncthreads();
+        cur ^= 1;
+        in_dim = Hh;
+    }
+    float* out = hidden_ws + ((size_t)head * R + r) * in_dim;
+    for (int k = threadIdx.x; k < in_dim; k += blockDim.x) out[k] = buf[cur][k];
+}
+
+// Destination index of element (r, kk, o) of the combined [W_msg; W_self] matrix of relation r
+// in FRAG16 order: Wfrag[r][o/16][kk/16][lane = ((kk%16)/4)*16 + o%16][kk%4], kk in [0, 2d).
+__device__ __forceinline__ size_t frag16_index(int r, int kk, int o, int d) {
+    const int NT = d >> 4, NJ2 = d >> 3;
+    return ((((size_t)r * NT + (o >> 4)) * NJ2 + (kk >> 4)) * 64 + (((kk & 15) >> 2) << 4) + (o & 15)) * 4 + (kk & 3);
+}
+
+// Vector-ALU last layer: one wave per output element n (lanes stride K), looping relations.
+// grid (ceil(n_out / 4)), block 256 (4 waves).
+__global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restrict__ z /* [R,Hl] */,
+                                                            const float* __restrict__ W3, const float* __restrict__ b3,
+                                                            const float* __restrict__ log_scale,
+                                                            int R, int Hl, int n_out, int head, int d_in, int d_out,
+                                                            int layout, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_out) return;
+    const float scale = expf(log_scale[0]);
+    const float bn = b3[n];
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
+        for (int k = lane; k < Hl; k += 64) s = fmaf(z[(size_t)r * Hl + k], W3[(size_t)n * Hl + k], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float v = (s + bn) * scale;
+            if (head == 2 || layout == GHF_WLAYOUT_NATURAL) {
+                out[(size_t)r * n_out + n] = v;
+            } else {
+                const int i = n / d_out, o = n - i * d_out;
+                out[frag16_index(r, head * d_in + i, o, d_out)] = v;
+            }
+        }
+    }
+}
+
+// MFMA last layer.  GEMM: D[m][c] = sum_k A[m][k] * B[k][c] with m = output element
+// (row n of W3), c = relation, k = hidden unit.  One wave computes a 16(m) x 16(c) tile per
+// relation tile; a workgroup of 4 waves covers 4 m-tiles.
+//  A fragment (v_mfma_f32_16x16x4_f32): lane l supplies A[row l&15][k = l>>4] per step.  Each lane
+//  loads 16 contiguous bytes W3[n(l&15)][16j + 4(l>>4) .. +3] and uses element s in step s,
+//  i.e. step (j,s) contracts k = 16j + 4(l>>4) + s: a permutation of k that the B side
+//  mirrors (B fragment: z[c = l&15][same k]).
+//  m-tile -> n mapping: NATURAL: n = 16*mt + row (contiguous).  FRAG16: an m-tile is 16
+//  consecutive input indices i for one output column o: n = (16*it + row)*d + o, so that a
+//  lane's 4 accumulator registers (rows 4q..4q+3) are the 4 consecutive kk of one fragment
+//  slot and are stored with one 16-byte store.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restrict__ z /* [R,Hl] */,
+                                                          const float* __restrict__ W3, const float* __restrict__ b3,
+                                                          const float* __restrict__ log_scale,
+                                                          int R, int Hl, int n_out, int head, int d,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int mt = blockIdx.x * 4 + wv;                 // m-tile index
+    if (mt * 16 >= n_out) return;
+    // row n handled by this lane as A-operand supplier (row = lane & 15)
+    int n_a;
+    int o = 0, it = 0;
+    if (LAYOUT == GHF_WLAYOUT_FRAG16) {
+        const int tiles_per_o = d >> 4;                  // i-tiles per output column
+        o = mt / tiles_per_o;
+        it = mt - o * tiles_per_o;
+        n_a = (16 * it + c16) * d + o;
+    } else {
+        n_a = 16 * mt + c16;
+    }
+    const bool a_ok = n_a < n_out;
+    const float* __restrict__ arow = W3 + (size_t)(a_ok ? n_a : 0) * Hl + 4 * q;
+    const float scale = expf(log_scale[0]);
+    const int NJ = Hl >> 4;
+
+    for (int r0 = 0; r0 < R; r0 += 16) {
+        const int rc = r0 + c16;                          // relation of this lane as B supplier / D column
+        const bool b_ok = rc < R;
+        const float* __restrict__ brow = z + (size_t)(b_ok ? rc : 0) * Hl + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 a = *(const f32x4*)(arow + 16 * j);
+            f32x4 b = *(const f32x4*)(brow + 16 * j);
+            if (!a_ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!b_ok) b = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+        }
+        // D layout: lane holds rows 4q + reg (reg 0..3), column c16 (= relation rc)
+        if (!b_ok) continue;
+        if (LAYOUT == GHF_WLAYOUT_FRAG16) {
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = (16 * it + 4 * q + s) * d + o;
+                v[s] = (acc[s] + b3[n]) * scale;
+            }
+            const int kk0 = head * d + 16 * it + 4 * q;   // kk of reg 0; kk & 3 == 0
+            *(f32x4*)(out + frag16_index(rc, kk0, o, d)) = v;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = 16 * mt + 4 * q + s;
+                if (n < n_out) out[(size_t)rc * n_out + n] = (acc[s] + b3[n]) * scale;
+            }
+        }
+    }
+}
+
+int launch_weightgen(const float* text_emb, const float* const* head_params, const float* log_scales,
+                     int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
+                     float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream) {
+    GHF_REQUIRE(R > 0 && T > 0 && d_in > 0 && d_out > 0, "weightgen: R, T, d_in, d_out must be positive");
+    GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
+    GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
+    GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
+    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16, "weightgen: bad layout %d", layout);
+    if (layout == GHF_WLAYOUT_FRAG16)
+        GHF_REQUIRE(d_in == d_out && (d_in % 16) == 0 && W_self == nullptr,
+                    "weightgen: FRAG16 needs d_in == d_out, d %% 16 == 0 and W_self == NULL");
+    else
+        GHF_REQUIRE(W_self != nullptr, "weightgen: NATURAL layout needs W_self");
+
+    HeadPtrs P;
+    const int nl = num_hidden + 1;
+    for (int h = 0; h < 3; ++h)
+        for (int l = 0; l < nl; ++l) {
+            P.w[h][l] = head_params[(h * nl + l) * 2 + 0];
+            P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
+            GHF_REQUIRE(P.w[h][l] && P.b[h][l], "weightgen: null parameter pointer (head %d layer %d)", h, l);
+        }
+    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, hidden_ws);
+    GHF_LAUNCH_CHECK();
+
+    const int Hl = num_hidden ? Hh : T;
+    const int n_mat = d_in * d_out;
+    for (int head = 0; head < 3; ++head) {
+        const float* z = hidden_ws + (size_t)head * R * Hl;
+        const float* W3 = P.w[head][num_hidden];
+        const float* b3 = P.b[head][num_hidden];
+        const int n_out = head == 2 ? d_out : n_mat;
+        float* out = head == 2 ? bias : (layout == GHF_WLAYOUT_FRAG16 ? W_msg : (head == 0 ? W_msg : W_self));
+        const bool mfma_ok = head != 2 && (Hl % 16) == 0 &&
+                             ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
+        if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
+            const int mtiles = n_mat / 16;
+            wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
+                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);
+        } else if (mfma_ok) {
+            const int mtiles = (n_mat + 15) / 16;
+            wg_out_mfma_kernel<GHF_WLAYOUT_NATURAL><<<(mtiles + 3) / 4, 256, 0, stream>>>(
+                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);
+        } else {
+            wg_out_simple_kernel<<<(n_out + 3) / 4, 256, 0, stream>>>(z, W3, b3, log_scales + head, R, Hl, n_out,
+                                                                      head, d_in, d_out, layout, out);
+        }
+        GHF_LAUNCH_CHECK();
+    }
+    return GHF_OK;
+}
+
+}  // namespace ghf

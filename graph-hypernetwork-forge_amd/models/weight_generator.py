@@ -1,0 +1,105 @@
+"""WeightGenerator — host mirror of the reference module, computing on MI355X.
+
+Same constructor, attributes, ``state_dict`` keys and output dict as
+``graph_hypernetwork_forge/models/weight_generator.py:50-143`` of the
+reference; ``forward`` runs the relation-batched HIP kernels of
+``csrc/weightgen.hip`` through the C ABI (``ghf_weightgen_fwd``) instead of
+three ``nn.Sequential`` stacks.  The ``nn.Linear`` modules exist to hold the
+parameters under the reference's names; they are never called.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _native
+
+HEADS: Tuple[str, ...] = ("W_msg", "W_self", "bias")     # reference weight_generator.py:72-76
+
+
+def require_inference(module: nn.Module, *tensors: torch.Tensor) -> None:
+    """The HIP path is forward-only (SURVEY.md §8f-1 lists backward as the next row)."""
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                f"{type(module).__name__} computes on an MI355X HIP device only (input is on {t.device}); "
+                "this package has no CPU or eager-PyTorch fallback")
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
+                                    any(p.requires_grad for p in module.parameters())):
+        raise NotImplementedError(
+            f"{type(module).__name__}: the HIP path implements the inference forward only; call it under "
+            "torch.no_grad() (or after .requires_grad_(False)). Training through it is not implemented yet.")
+
+
+class WeightGenerator(nn.Module):
+    """Generate ``(W_msg, W_self, bias)`` of one GNN layer from relation-text embeddings.
+
+    Args mirror the reference (weight_generator.py:50-59): ``text_dim, d_in,
+    d_out, hidden_dim=128, num_hidden=2, dropout=0.0, init_scale=0.01``.
+    """
+
+    def __init__(self, text_dim: int, d_in: int, d_out: int, hidden_dim: int = 128, num_hidden: int = 2,
+                 dropout: float = 0.0, init_scale: float = 0.01) -> None:
+        super().__init__()
+        if text_dim <= 0 or d_in <= 0 or d_out <= 0:             # reference :62-63
+            raise ValueError("text_dim, d_in, d_out must all be positive integers")
+        self.text_dim, self.d_in, self.d_out = text_dim, d_in, d_out
+        self.hidden_dim, self.num_hidden, self.dropout = hidden_dim, num_hidden, dropout
+        self.init_scale = init_scale
+        self._weight_specs: List[Tuple[str, Tuple[int, ...]]] = [
+            ("W_msg", (d_in, d_out)), ("W_self", (d_in, d_out)), ("bias", (d_out,))]
+
+        # Parameter containers laid out so that state_dict keys equal the reference's
+        # (generators.<head>.<idx>.{weight,bias}; idx steps by 3 when Dropout modules sit between).
+        self.generators = nn.ModuleDict()
+        for name, shape in self._weight_specs:
+            mods: List[nn.Module] = []
+            width = text_dim
+            for _ in range(num_hidden):
+                mods += [nn.Linear(width, hidden_dim), nn.ReLU()]
+                if dropout > 0.0:
+                    mods.append(nn.Dropout(dropout))
+                width = hidden_dim
+            last = nn.Linear(width, math.prod(shape))
+            nn.init.zeros_(last.bias)                              # reference :109-114
+            nn.init.normal_(last.weight, std=0.01)
+            mods.append(last)
+            self.generators[name] = nn.Sequential(*mods)
+        self.log_scales = nn.ParameterDict({
+            name: nn.Parameter(torch.full((1,), math.log(init_scale))) for name, _ in self._weight_specs})
+
+    # -- parameter packing for the C ABI ---------------------------------------------
+    def _linears(self, head: str) -> List[nn.Linear]:
+        return [m for m in self.generators[head] if isinstance(m, nn.Linear)]
+
+    def _head_params(self) -> List[torch.Tensor]:
+        flat: List[torch.Tensor] = []
+        for head in HEADS:
+            for lin in self._linears(head):
+                flat += [lin.weight.detach(), lin.bias.detach()]
+        return flat
+
+    def _log_scale_vector(self) -> torch.Tensor:
+        return torch.cat([self.log_scales[h].detach().reshape(1) for h in HEADS])
+
+    def generate(self, text_emb: torch.Tensor, layout: int = _native.WLAYOUT_NATURAL):
+        """[R,T] embeddings -> (W_msg | Wfrag, W_self | None, bias) device tensors in `layout`."""
+        return _native.weightgen_fwd(text_emb, self._head_params(), self._log_scale_vector(), self.text_dim,
+                                     self.hidden_dim, self.num_hidden, self.d_in, self.d_out, layout)
+
+    # -- public API (reference :120-143) -----------------------------------------------
+    def forward(self, text_emb: torch.Tensor) -> Dict[str, torch.Tensor]:
+        single = text_emb.dim() == 1
+        if text_emb.size(-1) != self.text_dim:
+            raise ValueError(f"text_emb has last dim {text_emb.size(-1)}, expected text_dim={self.text_dim}")
+        require_inference(self, text_emb)
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("WeightGenerator: dropout in training mode is not implemented on the HIP path")
+        x = text_emb.unsqueeze(0) if single else text_emb
+        W_msg, W_self, bias = self.generate(x.float())
+        out = {"W_msg": W_msg, "W_self": W_self, "bias": bias}
+        return {k: v.squeeze(0) for k, v in out.items()} if single else out

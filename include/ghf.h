@@ -1,0 +1,117 @@
+/* ghf.h — C ABI of libghf_hip.so: the MI355X (gfx950) HyperGNN forward hot path.
+ *
+ * The reference (danieleschmidt/Graph-Hypernetwork-Forge v0.2.0) has no FFI or
+ * plugin interface; its boundary for this path is two nn.Module call signatures
+ * (SURVEY.md §8b).  Each entry point below replaces a span of stock ATen CPU ops
+ * inside those two calls; the span is cited as reference file:line (paths
+ * relative to graph_hypernetwork_forge/).  The Python host mirror that binds
+ * these with ctypes is graph-hypernetwork-forge_amd/_native.py; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ *    caller (torch's caching allocator in the Python host).  Inputs are never
+ *    written.  Nothing is allocated, freed or synchronised inside any call.
+ *  - Every call enqueues on `stream` (a hipStream_t passed as void*) and returns
+ *    immediately; calls are re-entrant and graph-capturable.
+ *  - Return 0 on success, a negative GHF_E* code otherwise; ghf_last_error()
+ *    gives a thread-local message.
+ *  - All floating point is IEEE fp32; indices are int64 at the API (as in
+ *    models/hypergnn.py:191) and int32/uint32 inside a plan.
+ */
+#ifndef GHF_H
+#define GHF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GHF_ABI_VERSION 1
+
+#define GHF_OK            0
+#define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
+#define GHF_EHIP         -2   /* a HIP runtime call failed */
+#define GHF_EUNSUPPORTED -3   /* no kernel for this configuration */
+
+/* ghf_message_layer_fwd flags */
+#define GHF_FLAG_NO_TAIL  1   /* write sum_e(...) / max(indeg,1) only: skip residual+ReLU+LayerNorm */
+
+/* Weight layouts produced by ghf_weightgen_fwd and consumed by ghf_message_layer_fwd */
+#define GHF_WLAYOUT_NATURAL 0 /* W_msg[R][d_in][d_out], W_self[R][d_in][d_out] row-major, as the reference returns them */
+#define GHF_WLAYOUT_FRAG16  1 /* MFMA 16x16x4 B-fragment order: Wfrag[R][d/16][2d/16][64 lanes][4] */
+
+int         ghf_abi_version(void);
+const char* ghf_last_error(void);
+
+/* Which plan geometry and weight layout the message kernel for hidden size d wants.
+ * block_nodes == 1 means "CSR by destination" (the generic kernel). */
+int ghf_message_config(int d, int* block_nodes, int* wlayout);
+
+/* ---- K0: graph plan -----------------------------------------------------------
+ * Replaces the implicit edge order of models/hypergnn.py:191 (src,dst = edge_index)
+ * and the in-degree count of :207-212.  Sorts edges by (dst / block_nodes, rel,
+ * dst % block_nodes), i.e. key = (dst/BN)*R*BN + rel*BN + dst%BN, and emits
+ *   sorted_key [E] uint32, sorted_src [E] int32,
+ *   seg_off [nseg+1] int32 with nseg = ceil(N/BN)*R  (BN > 1)  or  N  (BN == 1: CSR rows),
+ *   indeg [N] int32,
+ *   status [1] int32: 0 ok, bit0 = a src/dst outside [0,N), bit1 = a rel outside [0,R)
+ *   (read it back before trusting the plan; offending edges are dropped).
+ * Requires ceil(N/BN)*BN*R < 2^32 and E < 2^31. */
+size_t ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes);
+int ghf_plan_build(const int64_t* edge_index /* [2,E] row 0 = src, row 1 = dst */,
+                   const int64_t* rel_id /* [E] */, int64_t N, int64_t E, int R, int block_nodes,
+                   void* workspace, size_t workspace_bytes,
+                   uint32_t* sorted_key, int32_t* sorted_src, int32_t* seg_off, int32_t* indeg,
+                   int32_t* status, void* stream);
+
+/* ---- K1: weight generation ------------------------------------------------------
+ * Replaces models/weight_generator.py:137-141 (three nn.Sequential heads, reshape,
+ * * exp(log_scale)) for B = R relation embeddings at once.
+ *  head_params: 3 heads (W_msg, W_self, bias) x (num_hidden+1) Linear layers x {weight,bias},
+ *               flattened as head_params[(head*(num_hidden+1) + layer)*2 + {0,1}];
+ *               weights are [out,in] row-major as nn.Linear stores them.
+ *  hidden_ws:   scratch for hidden activations, >= 3*2*R*max(Hh,T) floats.
+ *  layout NATURAL: W_msg,W_self [R,d_in,d_out], bias [R,d_out] (any d_in,d_out).
+ *  layout FRAG16:  requires d_in == d_out == d, d % 16 == 0; W_msg is the combined
+ *                  fragment buffer of 2*R*d*d floats and W_self must be NULL. */
+int ghf_weightgen_fwd(const float* text_emb /* [R,T] */, const float* const* head_params,
+                      const float* log_scales /* [3] device */, int R, int T, int Hh, int num_hidden,
+                      int d_in, int d_out, int layout, float* hidden_ws,
+                      float* W_msg, float* W_self, float* bias, void* stream);
+
+/* ---- input projection -------------------------------------------------------------
+ * Replaces models/hypergnn.py:261: h0 = relu(x @ W_in^T + b_in).  x [N,F], W_in [d,F]. */
+int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
+                       int64_t N, int F, int d, float* h0, void* stream);
+
+/* ---- K2+K3: one message-passing layer ---------------------------------------------
+ * Replaces models/hypergnn.py:281-296: per-edge weight gather, h_u @ W_msg[r] + bias[r],
+ * mean at targets, mean-W_self self-loop, residual, ReLU, LayerNorm — as
+ *   out_v = (1/max(indeg_v,1)) * sum_{e=(u->v)} (h_u W_msg[r_e] + bias[r_e] + h_v W_self[r_e])
+ *   h'_v  = LayerNorm(ReLU(out_v + h_v))              
+ * for destination rows [row0, row0+rows) (row0 % block_nodes == 0); other rows of
+ * h_out are not touched.  The plan arrays must come from ghf_plan_build with the
+ * same N, E, R, block_nodes; W/bias from ghf_weightgen_fwd with `wlayout`. */
+int ghf_message_layer_fwd(const float* h /* [N,d] */, int64_t N, int d,
+                          const uint32_t* sorted_key, const int32_t* sorted_src,
+                          const int32_t* seg_off, const int32_t* indeg,
+                          int64_t E, int R, int block_nodes,
+                          const float* W_msg, const float* W_self, const float* bias, int wlayout,
+                          const float* ln_gamma, const float* ln_beta, float ln_eps,
+                          int64_t row0, int64_t rows, float* h_out /* [N,d] */, int flags,
+                          void* stream);
+
+/* ---- K3 alone -------------------------------------------------------------------------
+ * Replaces models/hypergnn.py:288-296 on rows [row0,row0+rows): agg already holds
+ * out_v (GHF_FLAG_NO_TAIL output, e.g. after a cross-GPU reduction). */
+int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
+                 const float* ln_gamma, const float* ln_beta, float ln_eps,
+                 int64_t row0, int64_t rows, int d, float* h_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHF_H */

@@ -1,0 +1,109 @@
+"""Pin the oracle (oracle/hypergnn_oracle.py) to outputs of the real reference.
+
+The reference's own tests hold no numeric vectors; the fixtures in
+tests/golden/ were produced by importing the reference in the build container
+(tests/golden/make_golden.py).  These tests need no GPU.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from _util import assert_close
+from oracle import hypergnn_oracle as O
+
+SMALL = [n for n in cases.GRAPH_CASE_NAMES if n not in ("g5_c2", "g6_c3", "g6_c3_powerlaw", "g7_c5")]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"{name}.npz"))
+
+
+def _check_digest(g, params):
+    assert str(g["params_sha256"]) == cases.params_digest(params), \
+        "synthetic parameters drifted from the ones the fixture was generated with: rerun make_golden.py"
+
+
+@pytest.mark.parametrize("name", SMALL)
+@pytest.mark.parametrize("variant", ["reference", "factorised"])
+def test_forward_matches_reference(golden_dir, name, variant):
+    (case,) = cases.graph_cases(only=[name])
+    params = cases.MODELS[case.model].params()
+    g = _load(golden_dir, name)
+    _check_digest(g, params)
+    out, inter = O.forward(params, case.node_features, case.edge_index, case.edge_texts, variant=variant,
+                           return_intermediates=True)
+    assert_close(out.numpy(), g["out"], f"{name}/{variant}/out")
+    if case.intermediates:
+        assert_close(inter["text_embs"].numpy(), g["text_embs"], f"{name}/text_embs")
+        for l in range(cases.MODELS[case.model].num_layers):
+            for k in ("W_msg", "W_self", "bias"):
+                assert_close(inter[f"{k}{l}"].numpy(), g[f"{k}{l}"], f"{name}/{k}{l}", atol=1e-7)
+            assert_close(inter[f"h{l + 1}"].numpy(), g[f"h{l + 1}"], f"{name}/h{l + 1}")
+
+
+@pytest.mark.parametrize("name", ["g6_c3", "g6_c3_powerlaw", "g7_c5"])
+def test_forward_large_hidden_factorised(golden_dir, name):
+    (case,) = cases.graph_cases(only=[name])
+    params = cases.MODELS[case.model].params()
+    g = _load(golden_dir, name)
+    _check_digest(g, params)
+    out = O.forward(params, case.node_features, case.edge_index, case.edge_texts, variant="factorised")
+    assert_close(out.numpy(), g["out"], name)
+
+
+def test_forward_c2_sampled_rows(golden_dir):
+    (case,) = cases.graph_cases(only=["g5_c2"])
+    params = cases.MODELS[case.model].params()
+    g = _load(golden_dir, "g5_c2")
+    _check_digest(g, params)
+    out = O.forward(params, case.node_features, case.edge_index, case.edge_texts, variant="factorised").numpy()
+    assert tuple(g["out_shape"]) == out.shape
+    assert_close(out[g["rows"]], g["out_rows"], "g5_c2 sampled rows")
+    assert abs(np.linalg.norm(out.astype(np.float64)) - float(g["out_l2"])) <= 1e-5 * float(g["out_l2"])
+
+
+def test_fp64_ground_truth_is_closer_than_tolerance(golden_dir):
+    """The same algorithm in float64 agrees with the fp32 reference far inside the parity tolerance."""
+    (case,) = cases.graph_cases(only=["g3_mid32"])
+    params = cases.MODELS[case.model].params()
+    g = _load(golden_dir, "g3_mid32")
+    out64 = O.forward(params, case.node_features, case.edge_index, case.edge_texts, variant="factorised",
+                      dtype=torch.float64)
+    assert_close(out64.numpy(), g["out"], "fp64 vs reference")
+
+
+@pytest.mark.parametrize("c", cases.WG_CASES, ids=lambda c: c.name)
+def test_weight_generator_matches_reference(golden_dir, c):
+    g = np.load(os.path.join(golden_dir, "wg_cases.npz"))
+    params = c.params()
+    assert str(g[f"{c.name}/params_sha256"]) == cases.params_digest(params)
+    out = O.weight_generator(params, "", c.text_emb(), c.d_in, c.d_out)
+    for k in ("W_msg", "W_self", "bias"):
+        got = out[k].numpy()
+        if c.keep is not None:
+            got = got[list(c.keep)]
+        assert_close(got, g[f"{c.name}/{k}"], f"{c.name}/{k}", atol=1e-7)
+
+
+def test_tokenize_and_relation_ids():
+    assert O.tokenize("") == [0]
+    assert O.tokenize("aé東") == [97, 127, 127]
+    uniq, ids = O.relation_ids(["b", "a", "b", "c", "a"])
+    assert uniq == ["b", "a", "c"] and ids.tolist() == [0, 1, 0, 2, 1]
+
+
+def test_isolated_nodes_get_relu_layernorm_of_h():
+    """Nodes without in-edges: no message, no bias, no self term."""
+    torch.manual_seed(0)
+    h = torch.randn(6, 8)
+    ei = torch.tensor([[0, 1], [2, 2]])
+    rel = torch.tensor([0, 1])
+    Wm, Ws, b = torch.randn(2, 8, 8), torch.randn(2, 8, 8), torch.randn(2, 8)
+    out = O.message_passing_factorised(h, ei, rel, Wm, Ws, b)
+    assert torch.count_nonzero(out[[0, 1, 3, 4, 5]]) == 0
+    ref = O.message_passing_reference_shaped(h, ei, Wm[rel], Ws[rel], b[rel])
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
