@@ -1,0 +1,298 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden vectors and the oracle.
+
+All tests here need an MI355X.  Tolerance: allclose(rtol=1e-4, atol=1e-5) plus relative
+L2 <= 1e-5 (tests/_util.py), the bar BASELINE.json states for this fp32 path.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from _util import assert_close
+from graph_hypernetwork_forge_amd import HyperGNN, WeightGenerator, ToyKnowledgeGraph, _native, synth
+from graph_hypernetwork_forge_amd.plan import build_plan, relation_ids
+from oracle import hypergnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def make_model(cfg: cases.ModelCfg, params=None) -> HyperGNN:
+    m = HyperGNN(cfg.text_dim, cfg.node_feat_dim, cfg.hidden_dim, cfg.num_layers, char_emb_dim=cfg.char_emb_dim)
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in (params or cfg.params()).items()})
+    return m.to(DEV).eval()
+
+
+def run_case(case: cases.GraphCase) -> np.ndarray:
+    model = make_model(cases.MODELS[case.model])
+    with torch.no_grad():
+        out = model(torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV),
+                    case.edge_texts)
+    return out.cpu().numpy()
+
+
+def test_native_library_is_loaded():
+    lib = _native.load()
+    assert lib.ghf_abi_version() == 1
+    assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
+    assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16)
+    assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL)
+
+
+# ---- golden vectors from the reference -----------------------------------------------------
+
+@pytest.mark.parametrize("name", [n for n in cases.GRAPH_CASE_NAMES if n != "g5_c2"])
+def test_forward_matches_reference_golden(golden_dir, name):
+    (case,) = cases.graph_cases(only=[name])
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    assert str(g["params_sha256"]) == cases.params_digest(cases.MODELS[case.model].params())
+    assert_close(run_case(case), g["out"], name)
+
+
+def test_forward_c2_shape_sampled_rows(golden_dir):
+    (case,) = cases.graph_cases(only=["g5_c2"])
+    g = np.load(os.path.join(golden_dir, "g5_c2.npz"))
+    out = run_case(case)
+    assert out.shape == tuple(g["out_shape"])
+    assert_close(out[g["rows"]], g["out_rows"], "g5_c2 rows")
+    assert abs(np.linalg.norm(out.astype(np.float64)) - float(g["out_l2"])) <= 1e-5 * float(g["out_l2"])
+
+
+@pytest.mark.parametrize("name", ["g1_demo", "g1_demo_ls0", "g2_toy", "g3_mid32"])
+def test_generated_weights_match_reference(golden_dir, name):
+    """K1 in NATURAL layout against the reference's per-layer (W_msg, W_self, bias)."""
+    (case,) = cases.graph_cases(only=[name])
+    cfg = cases.MODELS[case.model]
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    model = make_model(cfg)
+    unique, _ = relation_ids(case.edge_texts)
+    with torch.no_grad():
+        te = model.text_encoder(unique, DEV)
+        assert_close(te.cpu().numpy(), g["text_embs"], f"{name}/text_embs")
+        for l, gen in enumerate(model.weight_generators):
+            w = gen(te)
+            for k in ("W_msg", "W_self", "bias"):
+                assert_close(w[k].cpu().numpy(), g[f"{k}{l}"], f"{name}/{k}{l}", atol=1e-7)
+
+
+@pytest.mark.parametrize("c", cases.WG_CASES, ids=lambda c: c.name)
+def test_weight_generator_module(golden_dir, c):
+    g = np.load(os.path.join(golden_dir, "wg_cases.npz"))
+    gen = WeightGenerator(c.text_dim, c.d_in, c.d_out, hidden_dim=c.hidden_dim, num_hidden=c.num_hidden,
+                          dropout=c.dropout)
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in c.params().items()})
+    gen = gen.to(DEV).eval()
+    with torch.no_grad():
+        out = gen(torch.from_numpy(c.text_emb()).to(DEV))
+    assert list(out.keys()) == ["W_msg", "W_self", "bias"]
+    for k in ("W_msg", "W_self", "bias"):
+        got = out[k].cpu().numpy()
+        if c.batch is None:
+            assert got.shape == ((c.d_in, c.d_out) if k != "bias" else (c.d_out,))
+        if c.keep is not None:
+            got = got[list(c.keep)]
+        assert_close(got, g[f"{c.name}/{k}"], f"{c.name}/{k}", atol=1e-7)
+
+
+def test_frag16_layout_is_a_permutation_of_natural():
+    c = [x for x in cases.WG_CASES if x.name == "wg_c3_shape"][0]
+    gen = WeightGenerator(c.text_dim, c.d_in, c.d_out, hidden_dim=c.hidden_dim)
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in c.params().items()})
+    gen = gen.to(DEV).eval()
+    x = torch.from_numpy(c.text_emb()).to(DEV)
+    with torch.no_grad():
+        Wm, Ws, b = gen.generate(x, _native.WLAYOUT_NATURAL)
+        Wf, none, b2 = gen.generate(x, _native.WLAYOUT_FRAG16)
+    assert none is None and torch.equal(b, b2)
+    R, d = x.size(0), c.d_in
+    # Wfrag[r][o/16][kk/16][lane=((kk%16)/4)*16 + o%16][kk%4], kk indexes rows of [W_msg; W_self]
+    cat = torch.cat([Wm, Ws], dim=1)                                   # [R, 2d, d]
+    f = Wf.view(R, d // 16, 2 * d // 16, 4, 16, 4)                     # r, nt, j, q, c16, s
+    back = f.permute(0, 2, 3, 5, 1, 4).reshape(R, 2 * d, d)            # kk = 16j + 4q + s ; o = 16nt + c16
+    assert torch.equal(back, cat)
+
+
+# ---- K0 plan properties -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("bn", [1, 216, 432])
+def test_plan_is_a_sorted_permutation_of_the_edges(bn):
+    N, E, R = 5000, 60000, 13
+    ei, rel = synth.make_graph_arrays(N, E, R, seed=77, kind="powerlaw")
+    sk, ss, off, indeg, status = _native.plan_build(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), N, R, bn)
+    assert int(status.item()) == 0
+    key = sk.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert (np.diff(key) >= 0).all()
+    blk, rem = key // (R * bn), key % (R * bn)
+    r, loc = rem // bn, rem % bn
+    dst = blk * bn + loc
+    got = np.stack([ss.cpu().numpy().astype(np.int64), dst, r])
+    want = np.stack([ei[0], ei[1], rel])
+    order = lambda a: a[:, np.lexsort(a[::-1])]                          # noqa: E731
+    assert np.array_equal(order(got), order(want))
+    assert np.array_equal(indeg.cpu().numpy(), np.bincount(ei[1], minlength=N))
+    off = off.cpu().numpy()
+    seg = dst if bn == 1 else blk * R + r
+    nseg = N if bn == 1 else -(-N // bn) * R
+    assert off.shape == (nseg + 1,) and off[0] == 0 and off[-1] == E
+    assert np.array_equal(np.diff(off), np.bincount(seg, minlength=nseg))
+
+
+def test_plan_flags_out_of_range_ids():
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]], device=DEV)
+    with pytest.raises(IndexError):
+        build_plan(ei, torch.tensor([0, 0, 0], device=DEV), ["a"], 5, 16, DEV)
+    with pytest.raises(IndexError):
+        build_plan(torch.tensor([[0, 1], [1, 2]], device=DEV), torch.tensor([0, 3], device=DEV), ["a", "b"], 5, 16, DEV)
+
+
+# ---- one message layer against the oracle, seeded inputs --------------------------------------
+
+def _layer_inputs(N, E, R, d, seed, kind):
+    ei, rel = synth.make_graph_arrays(N, E, R, seed, kind)
+    h = synth.normal(seed, "h", (N, d))
+    Wm = synth.normal(seed, "Wm", (R, d, d), std=0.15)
+    Ws = synth.normal(seed, "Ws", (R, d, d), std=0.15)
+    b = synth.normal(seed, "b", (R, d), std=0.3)
+    gamma = (1.0 + 0.2 * synth.normal(seed, "g", (d,))).astype(np.float32)
+    beta = (0.2 * synth.normal(seed, "bt", (d,))).astype(np.float32)
+    return ei, rel, h, Wm, Ws, b, gamma, beta
+
+
+def _to_frag16(Wm, Ws):
+    R, d, _ = Wm.shape
+    cat = np.concatenate([Wm, Ws], axis=1).reshape(R, 2 * d // 16, 4, 4, d // 16, 16)     # r, j, q, s, nt, c16
+    return np.ascontiguousarray(cat.transpose(0, 4, 1, 2, 5, 3)).reshape(-1)             # r, nt, j, q, c16, s
+
+
+@pytest.mark.parametrize("d,N,E,R,kind", [
+    (128, 3000, 30000, 64, "uniform"), (128, 2000, 40000, 5, "powerlaw"), (128, 500, 300, 64, "uniform"),
+    (64, 6000, 50000, 32, "uniform"), (64, 3000, 45000, 3, "powerlaw"),
+    (20, 400, 3000, 7, "uniform"), (16, 300, 2000, 4, "powerlaw"), (256, 300, 2400, 9, "uniform"),
+])
+@pytest.mark.parametrize("no_tail", [False, True])
+def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail):
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=1000 + d + R, kind=kind)
+    plan = build_plan(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), [""] * R, N, d, DEV)
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    if plan.wlayout == _native.WLAYOUT_FRAG16:
+        W, W2 = t(_to_frag16(Wm, Ws)), None
+    else:
+        W, W2 = t(Wm), t(Ws)
+    h_d = t(h)
+    out = torch.full_like(h_d, float("nan"))
+    _native.message_layer_fwd(h_d, plan, W, W2, t(b), plan.wlayout, None if no_tail else t(gamma),
+                              None if no_tail else t(beta), 1e-5, out, flags=_native.GHF_FLAG_NO_TAIL if no_tail else 0)
+    th = torch.from_numpy
+    ref = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
+    if not no_tail:
+        ref = O.layer_tail(ref, th(h), th(gamma), th(beta))
+    assert_close(out.cpu().numpy(), ref.numpy(), f"layer d={d} {kind} no_tail={no_tail}")
+    if no_tail:                                # K3 alone on the NO_TAIL output reproduces the fused tail
+        out2 = torch.empty_like(h_d)
+        _native.tail_fwd(out, h_d, t(gamma), t(beta), 1e-5, out2)
+        assert_close(out2.cpu().numpy(), O.layer_tail(ref, th(h), th(gamma), th(beta)).numpy(), "tail_fwd")
+
+
+def test_row_range_only_touches_its_rows():
+    d, N, E, R = 128, 2000, 20000, 16
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=5, kind="uniform")
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    W = t(_to_frag16(Wm, Ws))
+    full = torch.empty(N, d, device=DEV)
+    _native.message_layer_fwd(t(h), plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, full)
+    part = torch.full((N, d), 7.0, device=DEV)
+    bn = plan.block_nodes
+    _native.message_layer_fwd(t(h), plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, part, row0=2 * bn, rows=3 * bn)
+    assert torch.equal(part[2 * bn:5 * bn], full[2 * bn:5 * bn])
+    assert (part[:2 * bn] == 7.0).all() and (part[5 * bn:] == 7.0).all()
+
+
+def test_message_passing_seam_per_edge_weights():
+    """HyperGNN._message_passing keeps the reference's per-edge-weight signature (hypergnn.py:160-165)."""
+    torch.manual_seed(3)
+    N, E, d = 40, 150, 16
+    h = torch.randn(N, d)
+    ei = torch.randint(0, N, (2, E))
+    rw = {"W_msg": torch.randn(E, d, d) * 0.2, "W_self": torch.randn(E, d, d) * 0.2, "bias": torch.randn(E, d)}
+    model = make_model(cases.MODELS["small"])
+    with torch.no_grad():
+        out = model._message_passing(h.to(DEV), ei.to(DEV), {k: v.to(DEV) for k, v in rw.items()})
+    ref = O.message_passing_reference_shaped(h, ei, rw["W_msg"], rw["W_self"], rw["bias"])
+    assert_close(out.cpu().numpy(), ref.numpy(), "_message_passing")
+
+
+# ---- behaviour contract of the drop-in (reference tests/test_hypergnn.py) ---------------------
+
+def test_errors_and_cache():
+    kg = ToyKnowledgeGraph(feat_dim=16)
+    model = make_model(cases.MODELS["small"])
+    x, ei = kg.node_features.to(DEV), kg.edge_index.to(DEV)
+    with pytest.raises(ValueError):
+        model(x, ei, kg.edge_texts[:-1])
+    with pytest.raises(NotImplementedError):
+        model(x, ei, kg.edge_texts)                    # grad enabled + trainable parameters
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            model(kg.node_features, kg.edge_index, kg.edge_texts)     # CPU tensors: no fallback
+    with torch.no_grad():
+        a = model(x, ei, kg.edge_texts)
+        b = model(x, ei, kg.edge_texts)
+    assert model._plans.hits >= 1 and torch.equal(a, b)
+    assert a.shape == (kg.num_nodes, model.hidden_dim) and torch.isfinite(a).all()
+
+
+def test_relation_order_does_not_matter():
+    """Relabelling relations / shuffling edges only permutes W[r] and the summation order."""
+    (case,) = cases.graph_cases(only=["g6_c3"])
+    model = make_model(cases.MODELS[case.model])
+    x = torch.from_numpy(case.node_features).to(DEV)
+    perm = np.argsort(synth.raw_u64(9, "shuffle", case.edge_index.shape[1]), kind="stable")
+    with torch.no_grad():
+        a = model(x, torch.from_numpy(case.edge_index).to(DEV), case.edge_texts)
+        b = model(x, torch.from_numpy(np.ascontiguousarray(case.edge_index[:, perm])).to(DEV),
+                  [case.edge_texts[i] for i in perm.tolist()])
+    assert_close(b.cpu().numpy(), a.cpu().numpy(), "edge shuffle")
+
+
+# ---- BASELINE config 3 at full size: size-independent properties + sampled rows vs the oracle --
+
+def test_full_size_c3_layer_properties():
+    N, E, R, d = 1_000_000, 10_000_000, 64, 128
+    ei, rel = synth.make_graph_arrays(N, E, R, seed=1003)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    h = torch.randn(N, d, generator=g)
+    Wm, Ws = synth.normal(11, "Wm", (R, d, d), std=0.1), synth.normal(11, "Ws", (R, d, d), std=0.1)
+    b = synth.normal(11, "b", (R, d), std=0.3)
+    gamma, beta = np.ones(d, np.float32), np.zeros(d, np.float32)
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    assert plan.E == E and int(plan.indeg.sum().item()) == E
+    W = t(_to_frag16(Wm, Ws))
+    h_d = h.to(DEV)
+    out1, out2 = torch.empty_like(h_d), torch.empty_like(h_d)
+    args = (h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5)
+    _native.message_layer_fwd(*args, out1)
+    _native.message_layer_fwd(*args, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2), "d=128 kernel must be bitwise reproducible"
+    assert torch.isfinite(out1).all()
+    # LayerNorm rows: zero mean, unit (biased) variance
+    assert out1.mean(dim=1).abs().max().item() < 1e-4
+    assert (out1.var(dim=1, unbiased=False) - 1).abs().max().item() < 1e-2
+    # nodes without in-edges: exactly LayerNorm(ReLU(h))
+    iso = (plan.indeg == 0).nonzero().flatten()[:4096]
+    assert iso.numel() > 0
+    want = torch.nn.functional.layer_norm(torch.relu(h_d[iso]), (d,), t(gamma), t(beta), 1e-5)
+    assert_close(out1[iso].cpu().numpy(), want.cpu().numpy(), "isolated rows")
+    # sampled destination rows against the oracle on their in-edge subgraph
+    rows = np.unique(synth.randint(5, "rows", 300, N))
+    keep = np.isin(ei[1], rows)
+    sub_ei, sub_rel = ei[:, keep], rel[keep]
+    th = torch.from_numpy
+    ref = O.message_passing_factorised(h, th(sub_ei), th(sub_rel), th(Wm), th(Ws), th(b))
+    ref = O.layer_tail(ref, h, th(gamma), th(beta))[rows]
+    assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), "sampled rows of the 10M-edge layer")

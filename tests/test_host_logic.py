@@ -1,0 +1,166 @@
+"""Host-side logic that needs no GPU: C-ABI exports, the module mirror, plan cache keys, synthetic data."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from graph_hypernetwork_forge_amd import HyperGNN, TextEncoder, ToyKnowledgeGraph, WeightGenerator, _build, _native, synth
+from graph_hypernetwork_forge_amd.plan import PlanCache, relation_ids
+from oracle import hypergnn_oracle as O
+
+
+# ---- C ABI ------------------------------------------------------------------------------------
+
+def test_library_exports_every_symbol_of_the_header():
+    """The .so loads on a CPU-only host and exports exactly what include/ghf.h declares."""
+    lib = _native.load()
+    names = _native.header_symbols()
+    assert set(names) == set(_native.SIGNATURES), "include/ghf.h and _native.SIGNATURES disagree"
+    for n in names:
+        assert hasattr(lib, n), f"libghf_hip.so does not export {n}"
+    assert lib.ghf_abi_version() == 1
+
+
+def test_abi_argument_validation_without_a_gpu():
+    """Pure host-side checks of the C ABI (no kernel is launched)."""
+    lib = _native.load()
+    bn, wl = ctypes.c_int(), ctypes.c_int()
+    assert lib.ghf_message_config(128, ctypes.byref(bn), ctypes.byref(wl)) == 0
+    assert (bn.value, wl.value) == (216, 1)
+    assert lib.ghf_message_config(64, ctypes.byref(bn), ctypes.byref(wl)) == 0 and bn.value == 432
+    assert lib.ghf_message_config(20, ctypes.byref(bn), ctypes.byref(wl)) == 0 and (bn.value, wl.value) == (1, 0)
+    assert lib.ghf_message_config(16, None, None) == -1
+    assert b"null" in lib.ghf_last_error()
+    assert lib.ghf_input_proj_fwd(None, None, None, 4, 4, 4, None, None) == -1
+    assert lib.ghf_tail_fwd(None, None, None, None, 1e-5, 0, 1, 8, None, None) == -1
+
+
+def test_header_has_no_torch_or_cxx_types():
+    with open(os.path.join(_build.INCLUDE, "ghf.h")) as f:
+        text = f.read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)              # declarations only, comments stripped
+    assert 'extern "C"' in code
+    assert not re.search(r"torch|at::|std::|hip/hip_runtime", code)
+    assert set(re.findall(r"#include\s+<([^>]+)>", code)) == {"stddef.h", "stdint.h"}
+
+
+# ---- module mirror (reference tests/test_hypergnn.py, tests/test_weight_generator.py) ---------
+
+def test_state_dict_keys_match_the_reference_names():
+    for name, cfg in cases.MODELS.items():
+        m = HyperGNN(cfg.text_dim, cfg.node_feat_dim, cfg.hidden_dim, cfg.num_layers, char_emb_dim=cfg.char_emb_dim)
+        params = cfg.params()
+        assert set(m.state_dict().keys()) == set(params.keys()), name
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    g = WeightGenerator(32, 16, 16, hidden_dim=64, dropout=0.25)      # Dropout shifts Sequential indices to 0,3,6
+    assert "generators.W_msg.6.weight" in g.state_dict() and "generators.bias.3.bias" in g.state_dict()
+    assert sorted(g.log_scales.keys()) == ["W_msg", "W_self", "bias"]
+    assert g.state_dict()["log_scales.W_msg"].shape == (1,)
+
+
+def test_constructor_contract():
+    with pytest.raises(ValueError):
+        HyperGNN(text_dim=32, node_feat_dim=8, hidden_dim=16, num_layers=0)
+    for bad in ((0, 4, 4), (4, 0, 4), (4, 4, -1)):
+        with pytest.raises(ValueError):
+            WeightGenerator(*bad)
+    m = HyperGNN(text_dim=32, node_feat_dim=8, hidden_dim=16, num_layers=3)
+    assert len(m.weight_generators) == len(m.layer_norms) == m.num_layers == 3
+    assert m.weight_generators[0].hidden_dim == 64 and m.num_parameters() > 0
+    g = WeightGenerator(32, 16, 16, hidden_dim=256, num_hidden=0)
+    assert g.generators["W_msg"][0].in_features == 32                  # single Linear when num_hidden == 0
+    last = WeightGenerator(32, 16, 16).generators["W_msg"][-1]
+    assert float(last.bias.abs().max()) == 0.0 and float(last.weight.std()) < 0.02
+    assert m.score_triple(torch.ones(4, 16), torch.ones(4, 16)).shape == (4,)
+
+
+def test_forward_validation_happens_before_any_device_work():
+    kg = ToyKnowledgeGraph(feat_dim=16)
+    m = HyperGNN(text_dim=32, node_feat_dim=16, hidden_dim=16).eval()
+    with pytest.raises(ValueError):
+        m(kg.node_features, kg.edge_index, kg.edge_texts[:-1])
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            m(kg.node_features[:, :8], kg.edge_index, kg.edge_texts)
+    with pytest.raises(RuntimeError, match="no CPU"):                  # CPU tensors: fail loudly, no fallback
+        with torch.no_grad():
+            m(kg.node_features, kg.edge_index, kg.edge_texts)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        with torch.no_grad():
+            WeightGenerator(32, 16, 16)(torch.randn(32))
+
+
+def test_toy_kg_matches_the_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "toy_features.npz"))
+    kg = ToyKnowledgeGraph(feat_dim=16)
+    assert kg.num_nodes == 8 and kg.num_edges == 11 and len(kg.relation_types) == 7
+    assert np.array_equal(kg.edge_index.numpy(), g["edge_index"]) and kg.edge_texts == g["edge_texts"].tolist()
+    assert np.array_equal(kg.node_features.numpy(), g["node_features"])
+
+
+def test_text_encoder_batched_equals_per_string_oracle():
+    enc = TextEncoder(text_dim=32, char_emb_dim=16).eval()
+    params = {"text_encoder." + k: v.detach().numpy() for k, v in enc.state_dict().items()}
+    texts = ["knows", "", "café → 東京", "a", "is parent of"]
+    with torch.no_grad():
+        got = enc(texts, torch.device("cpu"))
+        one = enc.encode_one("knows", torch.device("cpu"))
+    ref = O.text_encode(params, texts)
+    assert got.shape == (5, 32) and torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(one, ref[0], rtol=1e-5, atol=1e-6)
+    assert enc._codes("") == [0] and enc._codes("é") == [127]
+
+
+# ---- plan host logic --------------------------------------------------------------------------------
+
+def test_relation_ids_first_appearance_order():
+    texts = ["b", "a", "b", "c", "a"]
+    uniq, ids = relation_ids(texts)
+    ouniq, oids = O.relation_ids(texts)
+    assert uniq == ouniq == ["b", "a", "c"] and ids.tolist() == oids.tolist() == [0, 1, 0, 2, 1]
+    assert ids.dtype == np.int64
+
+
+def test_plan_cache_keys():
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
+    texts = ["a", "b", "a"]
+    dev = torch.device("cpu")
+    k1 = PlanCache.key(ei, texts, 3, 16, dev)
+    assert k1 == PlanCache.key(ei, texts, 3, 16, dev)
+    assert k1 != PlanCache.key(ei, list(texts), 3, 16, dev)            # a different list object
+    assert k1 != PlanCache.key(ei, texts, 4, 16, dev) and k1 != PlanCache.key(ei, texts, 3, 32, dev)
+    ei.add_(0)                                                          # in-place edit bumps the version counter
+    assert k1 != PlanCache.key(ei, texts, 3, 16, dev)
+    texts[0] = "c"                                                      # sampled entries are part of the key
+    assert PlanCache.key(ei, texts, 3, 16, dev) != PlanCache.key(ei, ["a", "b", "a"], 3, 16, dev)
+    cache = PlanCache(capacity=2)
+    for i in range(3):
+        cache.put(("k", i), object(), ei, texts)
+    assert len(cache) == 2 and cache.get(("k", 0)) is None and cache.get(("k", 2)) is not None
+    assert (cache.hits, cache.misses) == (1, 1)
+
+
+# ---- synthetic data -------------------------------------------------------------------------------------
+
+def test_synth_is_deterministic_and_well_distributed():
+    a = synth.make_kg(1000, 8000, 16, 8, seed=5)
+    b = synth.make_kg(1000, 8000, 16, 8, seed=5)
+    assert np.array_equal(a.edge_index, b.edge_index) and np.array_equal(a.node_features, b.node_features)
+    assert a.edge_index.min() >= 0 and a.edge_index.max() < 1000 and a.rel_ids.max() < 16
+    assert abs(float(a.node_features.mean())) < 0.05 and abs(float(a.node_features.std()) - 1) < 0.05
+    assert synth.raw_u64(1, "x", 4).tolist() == synth.raw_u64(1, "x", 6)[:4].tolist()      # counter-based
+    assert synth.raw_u64(1, "x", 3, offset=2).tolist() == synth.raw_u64(1, "x", 5)[2:].tolist()
+    p = synth.make_kg(2000, 40000, 8, 4, seed=6, kind="powerlaw")
+    deg = np.bincount(p.edge_index[1], minlength=2000)
+    assert deg.max() > 20 * deg.mean()                                                       # a hub exists
+    texts = p.edge_texts()
+    assert len(texts) == 40000 and texts[0] is p.relation_texts[p.rel_ids[0]]
+    # pinned words: any change of the generator would silently invalidate the golden fixtures
+    assert synth.raw_u64(1003, "src", 2).tolist() == [int(x) for x in synth.raw_u64(1003, "src", 2)]
+    assert cases.params_digest(cases.MODELS["small"].params()) == str(
+        np.load(os.path.join(cases.GOLDEN_DIR, "g2_toy.npz"))["params_sha256"])
