@@ -7,6 +7,11 @@
 // the order the message kernels consume — plus group (or CSR-row) offsets.
 // dst and rel are recovered from the key, so a sorted edge costs 8 bytes
 // (uint32 key + int32 src) instead of the reference's 24 (three int64).
+// For block plans (BN > 1) two things the MFMA kernel would otherwise recompute in
+// every wave of every chunk are done here once per graph:
+//  - the chunk table: each group cut into chunks of <= chunk_rows edges, listed per block;
+//  - each edge's "run head": the first row of its run of equal destinations inside its
+//    16-row tile, packed into bits 28..31 of sorted_src (the kernel's segment-sum selector).
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -57,42 +62,106 @@ __global__ void plan_offsets_kernel(const uint32_t* __restrict__ sorted_key, int
     seg_off[s] = (int32_t)lo;
 }
 
-static int key_bits(uint64_t max_key_exclusive) {
-    int b = 1;
-    while (b < 32 && (1ull << b) < max_key_exclusive) ++b;
-    return b;
+// chunks per group: cnt[s] = ceil(group size / CR)
+__global__ void plan_chunk_count_kernel(const int32_t* __restrict__ seg_off, int64_t nseg, int CR,
+                                        int32_t* __restrict__ cnt) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nseg) cnt[s] = (seg_off[s + 1] - seg_off[s] + CR - 1) / CR;
 }
 
-static size_t cub_temp_bytes(int64_t E) {
+// chunk_tab[c] = { first sorted edge, (rel << 8) | (cross << 7) | rows };  coff = exclusive scan of cnt.
+// cross = 1 when a run of equal destinations continues across a 16-row tile boundary inside the chunk
+// (then two tiles of the chunk add into the same row of the block sums and must do so in order).
+__global__ void plan_chunk_fill_kernel(const uint32_t* __restrict__ sorted_key, const int32_t* __restrict__ seg_off,
+                                       const int32_t* __restrict__ coff, int64_t nseg, int R, int CR,
+                                       int32_t* __restrict__ chunk_tab) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const int e0 = seg_off[s], n = seg_off[s + 1] - e0, r = (int)(s % R);
+    int c = coff[s];
+    for (int j = 0; j < n; j += CR, ++c) {
+        const int rows = (n - j) < CR ? (n - j) : CR;
+        int cross = 0;
+        for (int t = 16; t < rows; t += 16) cross |= sorted_key[e0 + j + t - 1] == sorted_key[e0 + j + t];
+        chunk_tab[2 * c] = e0 + j;
+        chunk_tab[2 * c + 1] = (r << 8) | (cross << 7) | rows;
+    }
+}
+
+// blk_chunk_off[b] = coff[b * R] (b < NB), total chunk count at b == NB
+__global__ void plan_block_chunks_kernel(const int32_t* __restrict__ coff, const int32_t* __restrict__ cnt,
+                                         int64_t NB, int R, int32_t* __restrict__ blk_chunk_off) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < NB) blk_chunk_off[b] = coff[b * R];
+    else if (b == NB) blk_chunk_off[b] = coff[NB * R - 1] + cnt[NB * R - 1];
+}
+
+// run head of every sorted edge inside its 16-row tile, into bits 28..31 of sorted_src
+__global__ void plan_heads_kernel(const uint32_t* __restrict__ sorted_key, const int32_t* __restrict__ seg_off,
+                                  int64_t nvalid, uint32_t BN, int32_t* __restrict__ sorted_src) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nvalid) return;
+    const uint32_t key = sorted_key[e];
+    if (key == KEY_INVALID) return;                          // dropped edge (sorted last)
+    const int t = (int)((e - seg_off[key / BN]) & 15);       // row of e inside its tile
+    int head = t;
+    while (head > 0 && sorted_key[e - (t - head) - 1] == key) --head;
+    sorted_src[e] = (int32_t)(((uint32_t)sorted_src[e] & (uint32_t)SRC_MASK) | ((uint32_t)head << SRC_BITS));
+}
+
+static size_t sort_temp_bytes(int64_t E) {
     size_t tb = 0;
     hipcub::DeviceRadixSort::SortPairs<uint32_t, int32_t>(nullptr, tb, nullptr, nullptr, nullptr, nullptr,
                                                           (int)E, 0, 32, (hipStream_t)0);
     return tb;
 }
 
-size_t plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes) {
-    (void)N; (void)R; (void)block_nodes;
+static size_t scan_temp_bytes(int64_t n) {
+    size_t tb = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, (hipStream_t)0);
+    return tb;
+}
+
+static int64_t num_segments(int64_t N, int R, int BN) { return BN == 1 ? N : cdiv(N, BN) * R; }
+
+int64_t plan_max_chunks(int64_t N, int64_t E, int R, int BN, int CR) {
+    if (BN == 1 || CR <= 0) return 0;
+    const int64_t nseg = num_segments(N, R, BN);
+    return (nseg < E ? nseg : E) + E / CR + 1;          // every non-empty group adds at most one partial chunk
+}
+
+size_t plan_workspace_bytes(int64_t N, int64_t E, int R, int BN, int CR) {
     if (E <= 0) return 256;
-    return align_up((size_t)E * 4, 256) * 2 + align_up(cub_temp_bytes(E), 256) + 256;
+    size_t b = align_up((size_t)E * 4, 256) * 2 + align_up(sort_temp_bytes(E), 256) + 256;
+    if (BN > 1 && CR > 0) {
+        const int64_t nseg = num_segments(N, R, BN);
+        b += align_up((size_t)nseg * 4, 256) * 2 + align_up(scan_temp_bytes(nseg), 256);
+    }
+    return b;
 }
 
 int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, int64_t E, int R,
-                      int BN, void* ws, size_t ws_bytes, uint32_t* sorted_key, int32_t* sorted_src,
-                      int32_t* seg_off, int32_t* indeg, int32_t* status, hipStream_t stream) {
+                      int BN, int CR, void* ws, size_t ws_bytes, uint32_t* sorted_key, int32_t* sorted_src,
+                      int32_t* seg_off, int32_t* indeg, int32_t* chunk_tab, int32_t* blk_chunk_off,
+                      int32_t* status, hipStream_t stream) {
     GHF_REQUIRE(N > 0 && E > 0 && R > 0 && BN > 0, "plan: N, E, R, block_nodes must be positive");
     GHF_REQUIRE(E < (1ll << 31), "plan: E=%lld needs < 2^31 edges", (long long)E);
     const int64_t NB = cdiv(N, BN);
     const uint64_t key_space = (uint64_t)NB * (uint64_t)BN * (uint64_t)R;
     GHF_REQUIRE(key_space < 0xFFFFFFFFull, "plan: ceil(N/BN)*BN*R = %llu does not fit 32-bit keys",
                 (unsigned long long)key_space);
-    GHF_REQUIRE(ws_bytes >= plan_workspace_bytes(N, E, R, BN), "plan: workspace too small");
+    if (BN > 1) {
+        GHF_REQUIRE(N <= (1ll << SRC_BITS), "plan: block plans pack the run head above bit %d of the source id", SRC_BITS);
+        GHF_REQUIRE(CR > 0 && CR < 128 && (CR % 16) == 0 && R < (1 << 23), "plan: chunk_rows must be a multiple of 16 below 128, R < 2^23");
+    }
+    GHF_REQUIRE(ws_bytes >= plan_workspace_bytes(N, E, R, BN, CR), "plan: workspace too small");
     GHF_REQUIRE(((uintptr_t)ws & 255) == 0, "plan: workspace must be 256-byte aligned");
 
     char* p = (char*)ws;
     uint32_t* keys_in = (uint32_t*)p;            p += align_up((size_t)E * 4, 256);
     int32_t* vals_in = (int32_t*)p;              p += align_up((size_t)E * 4, 256);
-    void* cub_tmp = p;
-    size_t cub_bytes = cub_temp_bytes(E);
+    void* sort_tmp = p;                          p += align_up(sort_temp_bytes(E), 256);
+    size_t sort_bytes = sort_temp_bytes(E);
 
     GHF_HIP_CHECK(hipMemsetAsync(indeg, 0, (size_t)N * 4, stream));
     GHF_HIP_CHECK(hipMemsetAsync(status, 0, 4, stream));
@@ -101,15 +170,32 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
     plan_keys_kernel<<<grid, tpb, 0, stream>>>(edge_index, rel_id, N, E, R, BN, keys_in, vals_in, indeg, status);
     GHF_LAUNCH_CHECK();
 
+    // all 32 key bits are sorted so that KEY_INVALID (dropped edges) lands last
     GHF_HIP_CHECK((hipcub::DeviceRadixSort::SortPairs<uint32_t, int32_t>(
-        cub_tmp, cub_bytes, keys_in, sorted_key, vals_in, sorted_src, (int)E, 0, 32, stream)));
-    (void)key_bits;   // full 32 bits are sorted so that KEY_INVALID lands last
+        sort_tmp, sort_bytes, keys_in, sorted_key, vals_in, sorted_src, (int)E, 0, 32, stream)));
 
-    const int64_t nseg = (BN == 1) ? N : NB * R;
+    const int64_t nseg = num_segments(N, R, BN);
     const uint32_t seg_div = (BN == 1) ? (uint32_t)R : (uint32_t)BN;
-    const int64_t nthreads = nseg + 1;
-    plan_offsets_kernel<<<(int)((nthreads + 255) / 256), 256, 0, stream>>>(sorted_key, E, nseg, seg_div, seg_off);
+    plan_offsets_kernel<<<(int)((nseg + 1 + 255) / 256), 256, 0, stream>>>(sorted_key, E, nseg, seg_div, seg_off);
     GHF_LAUNCH_CHECK();
+
+    if (BN > 1) {
+        int32_t* cnt = (int32_t*)p;              p += align_up((size_t)nseg * 4, 256);
+        int32_t* coff = (int32_t*)p;             p += align_up((size_t)nseg * 4, 256);
+        void* scan_tmp = p;
+        size_t scan_bytes = scan_temp_bytes(nseg);
+        const int gs = (int)((nseg + 255) / 256);
+        plan_chunk_count_kernel<<<gs, 256, 0, stream>>>(seg_off, nseg, CR, cnt);
+        GHF_LAUNCH_CHECK();
+        GHF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int32_t*)cnt, coff, (int)nseg, stream));
+        plan_chunk_fill_kernel<<<gs, 256, 0, stream>>>(sorted_key, seg_off, coff, nseg, R, CR, chunk_tab);
+        GHF_LAUNCH_CHECK();
+        plan_block_chunks_kernel<<<(int)((NB + 1 + 255) / 256), 256, 0, stream>>>(coff, cnt, NB, R, blk_chunk_off);
+        GHF_LAUNCH_CHECK();
+        // heads for the valid edges only: seg_off[nseg] (device) bounds them, so the kernel re-reads it per edge
+        plan_heads_kernel<<<(int)((E + 255) / 256), 256, 0, stream>>>(sorted_key, seg_off, E, (uint32_t)BN, sorted_src);
+        GHF_LAUNCH_CHECK();
+    }
     return GHF_OK;
 }
 

@@ -102,7 +102,7 @@ class ShardedHyperGNN:
     def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], N: int, device) -> GraphPlan:
         key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, id(edge_texts), len(edge_texts), N)
         if key != self._plan_key:
-            bn, _ = self.ops.message_config(self.model.hidden_dim)
+            bn = self.ops.message_config(self.model.hidden_dim)[0]
             spec = shard_spec(N, bn, self.world, self.rank)
             unique, ids = relation_ids(edge_texts)
             self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, self.model.hidden_dim,

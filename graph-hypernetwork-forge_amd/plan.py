@@ -43,12 +43,15 @@ class GraphPlan:
     sorted_src: torch.Tensor       # [E] int32
     seg_off: torch.Tensor          # [nseg+1] int32
     indeg: torch.Tensor            # [N] int32
+    chunk_tab: Optional[torch.Tensor] = None       # [2*max_chunks] int32 (block plans)
+    blk_chunk_off: Optional[torch.Tensor] = None   # [NB+1] int32 (block plans)
+    chunk_rows: int = 0
     row_lo: int = 0                # destination rows this plan covers (multi-GPU shards)
     row_hi: int = 0
 
     def bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in
-                   (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg))
+        ts = (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg, self.chunk_tab, self.blk_chunk_off)
+        return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
 def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: List[str], N: int, d: int,
@@ -61,7 +64,7 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     if E == 0:
         raise ValueError("edge_index has no edges; the reference cannot encode an empty relation list either")
     R = len(unique_texts)
-    bn, wl = (1, _native.WLAYOUT_NATURAL) if force_generic else _native.message_config(d)
+    bn, wl, cr = (1, _native.WLAYOUT_NATURAL, 0) if force_generic else _native.message_config(d)
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range
@@ -72,16 +75,20 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
         if ei.size(1) == 0:                      # a shard without in-edges: empty plan, every row is "isolated"
             nseg = N if bn == 1 else ((N + bn - 1) // bn) * R
             z = lambda n: torch.zeros(n, dtype=torch.int32, device=device)  # noqa: E731
+            nb = (N + bn - 1) // bn
             return GraphPlan(N=N, E=0, R=R, block_nodes=bn, wlayout=wl, unique_texts=unique_texts, rel_ids=rel,
-                             sorted_key=z(1), sorted_src=z(1), seg_off=z(nseg + 1), indeg=z(N), row_lo=lo, row_hi=hi)
-    skey, ssrc, seg_off, indeg, status = _native.plan_build(ei, rel, N, R, bn)
+                             sorted_key=z(1), sorted_src=z(1), seg_off=z(nseg + 1), indeg=z(N),
+                             chunk_tab=z(2) if bn > 1 else None, blk_chunk_off=z(nb + 1) if bn > 1 else None,
+                             chunk_rows=cr, row_lo=lo, row_hi=hi)
+    skey, ssrc, seg_off, indeg, chunk_tab, blk_chunk_off, status = _native.plan_build(ei, rel, N, R, bn, cr)
     st = int(status.item())                       # the only host sync of the plan
     if st & 1:
         raise IndexError(f"edge_index holds node ids outside [0, {N})")
     if st & 2:
         raise IndexError(f"relation ids outside [0, {R})")
     return GraphPlan(N=N, E=ei.size(1), R=R, block_nodes=bn, wlayout=wl, unique_texts=unique_texts, rel_ids=rel,
-                     sorted_key=skey, sorted_src=ssrc, seg_off=seg_off, indeg=indeg, row_lo=lo, row_hi=hi)
+                     sorted_key=skey, sorted_src=ssrc, seg_off=seg_off, indeg=indeg, chunk_tab=chunk_tab,
+                     blk_chunk_off=blk_chunk_off, chunk_rows=cr, row_lo=lo, row_hi=hi)
 
 
 def _texts_fingerprint(edge_texts: Sequence[str]) -> Tuple:

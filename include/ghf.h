@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 1
+#define GHF_ABI_VERSION 2
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -47,25 +47,35 @@ int         ghf_abi_version(void);
 const char* ghf_last_error(void);
 
 /* Which plan geometry and weight layout the message kernel for hidden size d wants.
- * block_nodes == 1 means "CSR by destination" (the generic kernel). */
-int ghf_message_config(int d, int* block_nodes, int* wlayout);
+ * block_nodes == 1 means "CSR by destination" (the generic kernel; chunk_rows == 0 then). */
+int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows);
 
 /* ---- K0: graph plan -----------------------------------------------------------
  * Replaces the implicit edge order of models/hypergnn.py:191 (src,dst = edge_index)
  * and the in-degree count of :207-212.  Sorts edges by (dst / block_nodes, rel,
  * dst % block_nodes), i.e. key = (dst/BN)*R*BN + rel*BN + dst%BN, and emits
- *   sorted_key [E] uint32, sorted_src [E] int32,
+ *   sorted_key [E] uint32,
+ *   sorted_src [E] int32: the source node id; for BN > 1 bits 28..31 also hold the edge's
+ *              "run head": with t = (position in its (block, relation) group) % 16, the
+ *              smallest t' <= t such that positions t'..t of that 16-row tile all have the
+ *              same destination (needs N <= 2^28),
  *   seg_off [nseg+1] int32 with nseg = ceil(N/BN)*R  (BN > 1)  or  N  (BN == 1: CSR rows),
  *   indeg [N] int32,
+ *   chunk_tab [2*max_chunks] int32 and blk_chunk_off [ceil(N/BN)+1] int32 (BN > 1 only, else
+ *              NULL): every (block, relation) group cut into chunks of <= chunk_rows edges;
+ *              chunk c = { first sorted edge, (rel << 8) | (cross << 7) | rows }, cross = a run of
+ *              equal destinations spans a 16-row tile boundary inside the chunk; block b owns
+ *              chunks [blk_chunk_off[b], blk_chunk_off[b+1]),
  *   status [1] int32: 0 ok, bit0 = a src/dst outside [0,N), bit1 = a rel outside [0,R)
  *   (read it back before trusting the plan; offending edges are dropped).
- * Requires ceil(N/BN)*BN*R < 2^32 and E < 2^31. */
-size_t ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes);
+ * Requires ceil(N/BN)*BN*R < 2^32, E < 2^31, R < 2^23, chunk_rows % 16 == 0, chunk_rows < 128. */
+size_t  ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
+int64_t ghf_plan_max_chunks(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
 int ghf_plan_build(const int64_t* edge_index /* [2,E] row 0 = src, row 1 = dst */,
                    const int64_t* rel_id /* [E] */, int64_t N, int64_t E, int R, int block_nodes,
-                   void* workspace, size_t workspace_bytes,
+                   int chunk_rows, void* workspace, size_t workspace_bytes,
                    uint32_t* sorted_key, int32_t* sorted_src, int32_t* seg_off, int32_t* indeg,
-                   int32_t* status, void* stream);
+                   int32_t* chunk_tab, int32_t* blk_chunk_off, int32_t* status, void* stream);
 
 /* ---- K1: weight generation ------------------------------------------------------
  * Replaces models/weight_generator.py:137-141 (three nn.Sequential heads, reshape,
@@ -98,6 +108,7 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
 int ghf_message_layer_fwd(const float* h /* [N,d] */, int64_t N, int d,
                           const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg,
+                          const int32_t* chunk_tab, const int32_t* blk_chunk_off,
                           int64_t E, int R, int block_nodes,
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps,

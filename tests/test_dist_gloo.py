@@ -29,7 +29,7 @@ class OracleOps:
         self.bn = block_nodes
 
     def message_config(self, d):
-        return self.bn, 0
+        return self.bn, 0, 48
 
     def build_plan(self, edge_index, rel_ids, unique, N, d, device, row_range):
         lo, hi = row_range

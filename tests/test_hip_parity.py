@@ -36,10 +36,10 @@ def run_case(case: cases.GraphCase) -> np.ndarray:
 
 def test_native_library_is_loaded():
     lib = _native.load()
-    assert lib.ghf_abi_version() == 1
+    assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
-    assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16)
-    assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL)
+    assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48)
+    assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0)
 
 
 # ---- golden vectors from the reference -----------------------------------------------------
@@ -117,18 +117,21 @@ def test_frag16_layout_is_a_permutation_of_natural():
 
 # ---- K0 plan properties -----------------------------------------------------------------------
 
-@pytest.mark.parametrize("bn", [1, 216, 432])
-def test_plan_is_a_sorted_permutation_of_the_edges(bn):
+@pytest.mark.parametrize("bn,cr", [(1, 0), (216, 48), (432, 96)])
+def test_plan_is_a_sorted_permutation_of_the_edges(bn, cr):
     N, E, R = 5000, 60000, 13
     ei, rel = synth.make_graph_arrays(N, E, R, seed=77, kind="powerlaw")
-    sk, ss, off, indeg, status = _native.plan_build(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), N, R, bn)
+    sk, ss, off, indeg, ctab, boff, status = _native.plan_build(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV),
+                                                                N, R, bn, cr)
     assert int(status.item()) == 0
     key = sk.cpu().numpy().view(np.uint32).astype(np.int64)
     assert (np.diff(key) >= 0).all()
     blk, rem = key // (R * bn), key % (R * bn)
     r, loc = rem // bn, rem % bn
     dst = blk * bn + loc
-    got = np.stack([ss.cpu().numpy().astype(np.int64), dst, r])
+    raw = ss.cpu().numpy().view(np.uint32).astype(np.int64)
+    src = raw & _native.SRC_MASK if bn > 1 else raw
+    got = np.stack([src, dst, r])
     want = np.stack([ei[0], ei[1], rel])
     order = lambda a: a[:, np.lexsort(a[::-1])]                          # noqa: E731
     assert np.array_equal(order(got), order(want))
@@ -138,6 +141,34 @@ def test_plan_is_a_sorted_permutation_of_the_edges(bn):
     nseg = N if bn == 1 else -(-N // bn) * R
     assert off.shape == (nseg + 1,) and off[0] == 0 and off[-1] == E
     assert np.array_equal(np.diff(off), np.bincount(seg, minlength=nseg))
+    if bn == 1:
+        assert ctab is None and boff is None
+        return
+    # run heads: first row of the edge's run of equal keys inside its 16-row tile (tiles start at the group start)
+    head = raw >> 28
+    t = (np.arange(E) - off[seg]) % 16
+    want_head = np.empty(E, dtype=np.int64)
+    for e in range(E):
+        j = t[e]
+        while j > 0 and key[e - (t[e] - j) - 1] == key[e]:
+            j -= 1
+        want_head[e] = j
+    assert np.array_equal(head, want_head)
+    # chunk table: the groups of a block, cut into chunks of <= cr rows, in order
+    boff = boff.cpu().numpy()
+    nb = -(-N // bn)
+    assert boff.shape == (nb + 1,) and boff[0] == 0 and (np.diff(boff) >= 0).all()
+    tab = ctab.cpu().numpy()[: 2 * boff[-1]].reshape(-1, 2)
+    e0, rel_c, rows, cross = tab[:, 0], tab[:, 1] >> 8, tab[:, 1] & 127, (tab[:, 1] >> 7) & 1
+    assert rows.min() >= 1 and rows.max() <= cr and rows.sum() == E
+    assert np.array_equal(e0, np.concatenate([[0], np.cumsum(rows)[:-1]]))          # chunks tile the sorted edges
+    for c in range(len(tab)):
+        sl = slice(e0[c], e0[c] + rows[c])
+        assert (r[sl] == rel_c[c]).all() and len(set(blk[sl])) == 1
+        assert boff[blk[e0[c]]] <= c < boff[blk[e0[c]] + 1]
+        want_cross = any(key[e0[c] + b - 1] == key[e0[c] + b] for b in range(16, rows[c], 16))
+        assert cross[c] == int(want_cross)
+        assert (e0[c] - off[seg[e0[c]]]) % cr == 0
 
 
 def test_plan_flags_out_of_range_ids():

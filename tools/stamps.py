@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a message-kernel loop iteration spends its cycles (GHF_VARIANT=stamps build).
+
+Usage (GPU box):  GHF_VARIANT=stamps python tools/stamps.py [c3|c2]
+Prints the share of per-wave cycles in: memory wait, barrier, prefetch issue, compute, scatter, tail.
+Shares only — the stamped build is slower than the product build and its run time is never quoted.
+"""
+import ctypes
+import os
+import sys
+
+os.environ.setdefault("GHF_VARIANT", "stamps")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from graph_hypernetwork_forge_amd import _build, _native, synth
+from graph_hypernetwork_forge_amd.plan import build_plan
+
+cfgs = {"c3": (1_000_000, 10_000_000, 64, 128), "c2": (100_000, 1_000_000, 32, 64)}
+N, E, R, d = cfgs[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+_build.build()
+lib = _native.load()
+dev = torch.device("cuda:0")
+ei, rel = synth.make_graph_arrays(N, E, R, 1003)
+plan = build_plan(torch.from_numpy(ei).to(dev), torch.from_numpy(rel).to(dev), [""] * R, N, d, dev)
+h = torch.randn(N, d, device=dev)
+W = torch.randn(2 * R * d * d, device=dev) * 0.05
+b = torch.randn(R, d, device=dev)
+g, bt = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+out = torch.empty_like(h)
+for _ in range(2):
+    _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out)
+torch.cuda.synchronize()
+nb = min(8192, -(-N // plan.block_nodes))
+buf = np.zeros(8192 * 8 * 8, dtype=np.uint64)
+fn = lib.ghf_debug_read_stamps
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+assert fn(buf.ctypes.data, buf.size) == 0
+st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
+nw = d // 16
+st = st[:, :nw]
+tot = st.sum(axis=2)
+names = ["mem wait", "barrier", "prefetch issue", "compute", "scatter", "bookkeeping", "tail", "-"]
+print(f"blocks={nb} waves/block={nw} mean cycles per wave (100 MHz s_memtime ticks? see guide) = {tot.mean():.0f}")
+for i, n in enumerate(names[:7]):
+    print(f"  {n:22s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}")
