@@ -183,9 +183,17 @@ def main():
         byts = layer_bytes(N, E, R, d) * share
         tf = flops / (k_ms * 1e-3) / 1e12
         gbs = byts / (k_ms * 1e-3) / 1e9
-        roofline = {"kernel": "message_mfma_kernel<128>" if d == 128 else f"message kernel d={d}",
+        # HBM-side traffic per launch from the committed rocprofv3 PMC passes of this same command (separate
+        # --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_message_kernel_pmc.json")
+        if args.workload == "c3" and world == 1 and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            traffic_src = "profiles/r01_message_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2)"
+        roofline = {"kernel": "message_pp_kernel<128>" if d == 128 else f"message_mfma_kernel<{d}>",
                     "bound": "mfma", "achieved": tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": tf / FP32_MATRIX_PEAK_TF, "traffic": None,
+                    "frac": tf / FP32_MATRIX_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
                     "ms_per_launch": k_ms, "algorithmic_flops_per_launch": flops,
                     "algorithmic_bytes_per_launch": byts,
                     "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},

@@ -86,6 +86,7 @@ struct MsgArgs {
 };
 int launch_message_generic(const MsgArgs& a, hipStream_t stream);
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
+int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)
 bool message_mfma_config(int d, int* block_nodes, int* chunk_rows);
 
 int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,

@@ -1,0 +1,498 @@
+// message_pp.hip — K2+K3, "ping-pong" schedule (hidden size 128).
+//
+// Same math, plan, LDS layout and results as message_mfma.hip (see its header for the geometry: a workgroup owns
+// BN destination nodes and their fp32 sums in LDS; a chunk = <= 48 rows of one relation = a small GEMM run as two
+// K-phases from an LDS A tile and register B fragments; segment-sum MFMA + plain LDS read-add-write into the sums;
+// fused tail).  What differs is WHO does WHAT between two barriers.
+//
+// In message_mfma.hip all 8 waves run the same program, so the two waves that share a SIMD reach their non-MFMA
+// segments (prefetch issue, waits, barrier, scatter) together and the SIMD's matrix pipe idles there: stamped 66 %
+// busy, 8.0 ms even with the scatter removed, against a 5.3 ms MFMA floor.
+// Here the 8 waves form two TEAMS of 4 (one wave per SIMD each; waves w and w+4 share a SIMD).  A wave owns 32
+// output columns (2 fragments), so one team covers all 128.  Teams take alternate chunks and alternate ROLES every
+// barrier interval:
+//      interval g     team g&1      : MFMA   — one K-phase of its chunk, nothing but ds_read + v_mfma
+//                     the other team: PREP   — scatter of its finished chunk, LDS-DMA gather of its next A tile,
+//                                              B-fragment / index / descriptor loads, then s_waitcnt vmcnt(0)
+// so each SIMD always has one wave feeding the matrix pipe while its partner absorbs every memory latency.
+// Each team has its own A tile (the two tiles of the old double buffer), B fragments are loaded in PREP into the
+// registers the team's previous MFMA interval just released (no double buffering of B), and no global load is ever
+// issued inside an MFMA interval.  Scatters of the two teams never overlap in time (they are in different
+// intervals), and a team scatters its chunks in order, so the sums are still bitwise reproducible.
+#include "common.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace ghf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int PP_WAIT_VMCNT0 = 0x0F70;      // s_waitcnt vmcnt(0) only (builtin form: modelled by hipcc)
+
+// uniform base + 32-bit byte offset: lets the backend use the SGPR-base addressing form (one VGPR per address);
+// with 64-bit per-lane pointers the loop-invariant parts hoisted out of the chunk loop spilled.  All arrays
+// indexed this way are < 4 GiB here (checked by the launcher).
+template <class T>
+__device__ __forceinline__ const T* at(const void* base, uint32_t byte_off) {
+    return (const T*)((const char*)base + byte_off);
+}
+
+// Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals, as in message_mfma.hip
+#ifdef GHF_STAMPS
+__device__ unsigned long long ghf_pp_stamp_buf[8192 * 8 * 8];
+#define PP_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0
+#define PP_STAMP(i)                                                                            \
+    do {                                                                                       \
+        unsigned long long _t;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((i) >= 0) st_acc[(i) < 0 ? 0 : (i)] += _t - st_last;                               \
+        st_last = _t;                                                                          \
+    } while (0)
+#else
+#define PP_STAMP_DECL
+#define PP_STAMP(i)
+#endif
+
+template <int D> struct PpCfg;
+template <> struct PpCfg<128> { static constexpr int BN = 216, MTC = 3; };
+
+struct PpChunk { int r; int e0; int rows; int cross; };     // rows == 0: none
+
+template <int D>
+__global__ __launch_bounds__(512) void message_pp_kernel(
+    const float* __restrict__ h, int64_t N, const uint32_t* __restrict__ sorted_key,
+    const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
+    const int32_t* __restrict__ blk_chunk_off, const int32_t* __restrict__ indeg, int R,
+    const float* __restrict__ Wfrag, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    int64_t row0, int64_t row_end, float* __restrict__ h_out, int no_tail) {
+    using C = PpCfg<D>;
+    constexpr int BN = C::BN, MTC = C::MTC;
+    constexpr int NWV = 8, TW = 4;            // waves per workgroup, per team
+    constexpr int NJ = D / 16;                // k-groups of 16 per phase
+    constexpr int NT = D / 16;                // 16-column fragments of the output
+    constexpr int NTW = NT / TW;              // fragments per wave (2)
+    constexpr int NJ2 = 2 * NJ;
+    constexpr int CPR = D / 4;                // 16-byte chunks per A row
+    constexpr int RPI = 256 / D;              // A rows per 1 KiB LDS-DMA wave-instruction
+    constexpr int CR = 16 * MTC;              // rows per chunk
+    constexpr int IPW = CR / RPI / TW;        // LDS-DMA instructions per wave per stage (6)
+    static_assert(NTW * TW == NT && CR % (RPI * TW) == 0 && MTC == 3, "bad tile config");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* acc_lds = (float*)smem;                    // [BN + 4][D]: block sums + 4 dummy rows
+    float* Abase = acc_lds + (BN + 4) * D;            // [2 teams][CR][D], 16-byte chunks XOR-swizzled by (row & 15)
+    int* s_meta = (int*)(Abase + 2 * CR * D);         // [2 teams][CR] row words: (target row << 4) | run head
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = w >> 2, tw = w & 3;              // waves w and w+4 share a SIMD: one of each team per SIMD
+    const int q = lane >> 4, c16 = lane & 15;
+    const int64_t blk = row0 / BN + blockIdx.x;
+    const int64_t node0 = blk * BN;
+    const int nrows = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
+    const uint32_t seg0 = (uint32_t)(blk * R);
+    float* const Abuf = Abase + team * CR * D;        // this team's A tile
+    int* const meta = s_meta + team * CR;             // this team's row words
+
+    for (int i = tid; i < (BN + 4) * D / 4; i += NWV * 64) ((f32x4*)acc_lds)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * CR; i += NWV * 64) s_meta[i] = ((BN + ((i >> 2) & 3)) * (D * 4)) | (i & 15);
+
+    PP_STAMP_DECL;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));    // opaque 0: keeps the descriptor loads on the vector path
+    const int c_begin = __builtin_amdgcn_readfirstlane(blk_chunk_off[blk]);
+    const int c_end = __builtin_amdgcn_readfirstlane(blk_chunk_off[blk + 1]);
+    const int nchunks = c_end - c_begin;
+    const int my_chunks = (nchunks - team + 1) >> 1;   // chunks c_begin + team, + team + 2, ...
+    const int my_steps = 2 * my_chunks;                // a step = one K-phase of one of my chunks
+    const int steps0 = 2 * ((nchunks + 1) >> 1);       // team 0 never has fewer chunks than team 1
+
+    auto load_desc = [&](int c) -> i32x2 {
+        const int cc = (c < c_end ? c : c_begin) + vzero;               // clamp: a valid (ignored) entry
+        return *at<i32x2>(chunk_tab, (uint32_t)cc * 8u);
+    };
+    auto decode = [&](i32x2 d, int c) -> PpChunk {
+        const int w0 = __builtin_amdgcn_readfirstlane(d[0]), w1 = __builtin_amdgcn_readfirstlane(d[1]);
+        return c < c_end ? PpChunk{w1 >> 8, w0, w1 & 127, (w1 >> 7) & 1} : PpChunk{0, 0, 0, 0};
+    };
+
+    // A chunk's plan words, lane = row: ONE vector load per array per chunk (a vector-memory instruction issued
+    // beside the SIMD partner's MFMA stream costs ~250 cycles here, so six per-piece index loads per PREP were
+    // most of it); the DMA pieces pick their rows' words out of these registers with lane shuffles.
+    struct Words { int src; int key; };
+    auto load_words = [&](const PpChunk& c) -> Words {
+        const int rc = lane < c.rows ? lane : c.rows - 1;                   // rows >= 1 here; pad lanes repeat the last row
+        const uint32_t eo = (uint32_t)(c.e0 + rc) * 4u;
+        return Words{*at<int>(sorted_src, eo), *at<int>(sorted_key, eo)};
+    };
+
+    // Gather the (chunk, phase) A tile into this team's buffer, register-staged: the 16-byte loads are issued early
+    // in PREP (stage_load) and written to LDS at its end (stage_commit), after the scatter has covered their latency.
+    // (LDS-DMA, used by message_mfma.hip where no MFMA runs during the issue, stamped ~450 cycles per instruction to
+    // issue from a wave whose SIMD partner streams MFMAs: 2,700 of a 6,700-cycle PREP.)  The LDS image is the same:
+    // 16-byte chunks XOR-swizzled by (row & 15) via the SOURCE address, rows linear.  Phase 1 also publishes the
+    // chunk's row words: (byte offset of the row's target in the block sums) | run head.  Every instruction here
+    // competes with the partner's MFMA stream for issue, so the code is branch-free: all CR rows are gathered (pad
+    // rows repeat the last live row: an L2 hit), shuffles first, one wait, then the loads.
+    f32x4 stg[IPW];
+    auto stage_load = [&](const PpChunk& c, int ph, const Words& wd) {
+        const uint32_t kbase = (seg0 + (uint32_t)c.r) * (uint32_t)BN;
+        if (ph == 1 && tw == 0 && lane < CR) {
+            const int head = (int)((uint32_t)wd.src >> SRC_BITS), row16 = lane & 15;
+            const bool live = lane < c.rows;
+            const int tgt = (live && head == row16) ? (int)((uint32_t)wd.key - kbase) : BN + ((lane >> 2) & 3);
+            meta[lane] = (tgt * (D * 4)) | (live ? head : row16);          // D*4 = 512: the low 4 bits stay free
+        }
+        const int word = ph == 0 ? wd.src : wd.key;
+        int v[IPW];
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) v[i] = __shfl(word, (tw * IPW + i) * RPI + lane / CPR, 64);
+        PP_STAMP(5);                                    // (diagnostic) row words + shuffles
+        const uint32_t nbase = ph == 0 ? 0u : (uint32_t)node0 - kbase;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int rho = (tw * IPW + i) * RPI + lane / CPR;             // LDS row this lane fills
+            const uint32_t node = (ph == 0 ? (uint32_t)(v[i] & SRC_MASK) : (uint32_t)v[i]) + nbase;
+            stg[i] = *at<f32x4>(h, node * (uint32_t)(D * 4) + (uint32_t)(((lane % CPR) ^ (rho & 15)) << 4));
+        }
+        PP_STAMP(7);                                    // (diagnostic) gather issue
+    };
+    auto stage_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) *(f32x4*)(Abuf + (tw * IPW + i) * 256 + lane * 4) = stg[i];
+    };
+
+    // B fragments of (relation r, phase ph): byte offset of k-group 0 of this wave's first fragment
+    auto b_off = [&](int r, int ph, int t) -> uint32_t {
+        return (uint32_t)((r * NT + tw * NTW + t) * NJ2 + ph * NJ) * 1024u + (uint32_t)lane * 16u;
+    };
+    constexpr int BPRE = 2;                            // k-groups of B requested ahead (end of my previous interval); the rest just in time
+    auto load_b_head = [&](int r, int ph, f32x4 (&b)[NJ][NTW]) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int j = 0; j < BPRE; ++j) b[j][t] = *at<f32x4>(Wfrag, b_off(r, ph, t) + (uint32_t)j * 1024u);
+    };
+
+    f32x4 acc[MTC][NTW];
+    f32x4 b[NJ][NTW];
+
+    // MFMA interval: one K-phase of the chunk; M = live row tiles (compile-time per variant).
+    //  - A fragments of k-group j+1 are read while the MFMAs of k-group j run (explicit two-stage pipeline).
+    //  - B fragments: k-groups 0..BPRE-1 arrive from PREP; k-group j+BPRE is requested while k-group j computes.
+    //    A vector-memory instruction issued by the SIMD partner beside this MFMA stream cost it 100-185 cycles
+    //    each (stamped: 7,150 cycles of PREP issue per interval with all 16 B loads there); issued from inside the
+    //    stream it costs ~60, and only BPRE+1 k-groups of B are live at a time (24 VGPRs instead of 64).
+    auto compute_tiles = [&](auto Mtag, int r, int ph) {
+        constexpr int M = decltype(Mtag)::value;
+        uint32_t boff[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) boff[t] = b_off(r, ph, t);
+        f32x4 a[2][M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) a[0][m] = *(const f32x4*)(Abuf + (m * 16 + c16) * D + ((q ^ c16) << 2));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j + BPRE < NJ) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b[j + BPRE][t] = *at<f32x4>(Wfrag, boff[t] + (uint32_t)(j + BPRE) * 1024u);
+            }
+            if (j + 1 < NJ) {
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+                    a[(j + 1) & 1][m] = *(const f32x4*)(Abuf + (m * 16 + c16) * D + (((4 * (j + 1) + q) ^ c16) << 2));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j & 1][m][s], b[j][t][s], acc[m][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // PREP: segment-sum finished rows by destination into this wave's column strips, tiles [M0, M1).
+    // x = the rows (acc, or the copy kept for the deferred tile), mq = their row words.
+    auto scatter_tiles = [&](auto M0tag, auto M1tag, f32x4 (&x)[MTC][NTW], const i32x4 (&mq)[MTC]) {
+        constexpr int M0 = decltype(M0tag)::value, M1 = decltype(M1tag)::value;
+        f32x4 y[MTC][NTW];
+        const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16);
+#pragma unroll
+        for (int m = M0; m < M1; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) y[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)                                          // independent chains, interleaved
+#pragma unroll
+            for (int m = M0; m < M1; ++m) {
+                const float sel = ((mq[m][s] & 15) == c16) ? 1.0f : 0.0f;   // S[i = c16][k = 4q + s] = (head(k) == i)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    y[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, x[m][t][s], y[m][t], 0, 0, 0);
+            }
+        // plain LDS read-add-write through inline asm (see message_mfma.hip), tile by tile: a run of equal
+        // destinations may continue into the next tile, and 8 loads per tile keep the LDS pipe busy anyway
+#pragma unroll
+        for (int m = M0; m < M1; ++m) {
+            float v[NTW][4];
+            unsigned addr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) addr[s] = strip + ((unsigned)mq[m][s] & ~15u);           // the run's target row, or a dummy
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[t][s]) : "v"(addr[s]), "n"(t * 64) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]),
+                           "+v"(v[NTW - 1][0]), "+v"(v[NTW - 1][1]), "+v"(v[NTW - 1][2]), "+v"(v[NTW - 1][3])
+                         :: "memory");
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr[s]), "v"(v[t][s] + y[m][t][s]), "n"(t * 64) : "memory");
+        }
+    };
+    auto load_row_words = [&](i32x4 (&mq)[MTC]) {
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) mq[m] = *(const i32x4*)(meta + m * 16 + 4 * q);
+    };
+
+    // ---- team state --------------------------------------------------------------------------------------------
+    int kc = c_begin + team;                           // index of my current chunk `ch`
+    PpChunk ch = decode(load_desc(kc), kc);
+    PpChunk ch_next{0, 0, 0, 0};
+    i32x2 d_next = load_desc(kc + 2);
+    Words wd{0, 0}, wd_next{0, 0};                     // plan words of `ch` / of my next chunk
+    float bias_v[NTW] = {0.f, 0.f};
+    int pending = 0;                                   // live row tiles of my finished, not yet scattered chunk
+
+    // The scatter of a finished chunk is split over my next two PREPs so that neither exceeds the partner's MFMA
+    // interval (a PREP instruction gets about one issue slot per partner MFMA): tiles 0..1 in the phase-0 PREP,
+    // tile 2 — rows and row words copied to registers there — in the phase-1 PREP.
+    f32x4 x2[MTC][NTW];                                // only [MTC-1] is used: the deferred tile's rows
+    i32x4 mq2[MTC];                                    // only [MTC-1] is used: its row words
+    int deferred = 0;
+
+    // PREP before a phase-0 MFMA interval: move to my next chunk and request what its phase 0 needs FIRST, then
+    // scatter (part of) the chunk that just finished while those loads are in flight.
+    auto prep_ph0 = [&]() {
+        __builtin_amdgcn_s_setprio(3);                  // PREP is short, latency-critical work beside the partner's MFMA stream
+        const int pend = pending;
+        if (pend) {
+            pending = 0;
+            ch = ch_next;                              // decoded, and its words loaded, in my previous PREP
+            wd = wd_next;
+            kc += 2;
+        }
+        const bool staged = ch.rows != 0;
+        if (staged) {
+            stage_load(ch, 0, wd);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bias_v[t] = *at<float>(bias, (uint32_t)(ch.r * D + (tw * NTW + t) * 16 + c16) * 4u);
+            d_next = load_desc(kc + 2);
+        }
+        asm volatile("" ::: "memory");
+        PP_STAMP(2);                                    // prep: issue
+        if (pend) {                                    // consumes registers and LDS only: nothing just requested
+            i32x4 mq[MTC];
+            load_row_words(mq);
+            scatter_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, MTC - 1>{}, acc, mq);
+            mq2[MTC - 1] = mq[MTC - 1];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) x2[MTC - 1][t] = acc[MTC - 1][t];
+            deferred = pend == MTC;                    // a dead last tile carries zeros into dummy rows: skip it
+        }
+        PP_STAMP(3);                                    // prep: scatter
+        if (staged) stage_commit();
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_waitcnt(PP_WAIT_VMCNT0);     // everything landed before the barrier that hands it over
+        PP_STAMP(4);                                    // prep: wait for memory + LDS commit
+    };
+    // PREP before a phase-1 MFMA interval
+    auto prep_ph1 = [&]() {
+        __builtin_amdgcn_s_setprio(3);
+        const bool staged = ch.rows != 0;
+        if (staged) {
+            stage_load(ch, 1, wd);
+            ch_next = decode(d_next, kc + 2);          // loaded one PREP ago
+            if (ch_next.rows) wd_next = load_words(ch_next);
+        }
+        PP_STAMP(2);
+        if (deferred) {
+            scatter_tiles(std::integral_constant<int, MTC - 1>{}, std::integral_constant<int, MTC>{}, x2, mq2);
+            deferred = 0;
+        }
+        PP_STAMP(3);
+        if (staged) stage_commit();
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_waitcnt(PP_WAIT_VMCNT0);
+        PP_STAMP(4);
+    };
+    auto mfma_phase = [&](int ph) {
+        PP_STAMP(0);                                    // barrier wait
+        if (!ch.rows) return;
+        const int mt = (ch.rows + 15) >> 4;
+        if (ph == 0) {
+#pragma unroll
+            for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (mt == 3) compute_tiles(std::integral_constant<int, 3>{}, ch.r, ph);
+        else if (mt == 2) compute_tiles(std::integral_constant<int, 2>{}, ch.r, ph);
+        else compute_tiles(std::integral_constant<int, 1>{}, ch.r, ph);
+        if (ph == 1) {                                 // finish the rows: bias[r] once per edge row; dead tiles -> zeros
+#pragma unroll
+            for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[m][t] = m < mt ? acc[m][t] + bias_v[t] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            pending = mt;
+        }
+        // the first B fragments of my NEXT step, requested here at the end of my interval (my SIMD partner is in
+        // PREP, no MFMA stream to compete with); they land during my own PREP, which ends with vmcnt(0)
+        if (ph == 0) load_b_head(ch.r, 1, b);
+        else if (ch_next.rows) load_b_head(ch_next.r, 0, b);
+        PP_STAMP(1);                                    // mfma interval
+    };
+
+    if (ch.rows) {
+        wd = load_words(ch);
+        load_b_head(ch.r, 0, b);
+    }
+    __syncthreads();                                   // sums zeroed, row words initialised
+    PP_STAMP(-1);
+
+    // Two static programs, one per team, offset by one barrier interval; both execute 4*iters + 1 barriers.
+    //   interval:   4i        4i+1      4i+2      4i+3
+    //   team 0:     MFMA ph0  PREP ph1  MFMA ph1  PREP ph0 (scatter + next chunk)
+    //   team 1:     PREP ph0  MFMA ph0  PREP ph1  MFMA ph1
+    const int iters = (nchunks + 1) >> 1;              // team 0 never has fewer chunks than team 1
+    if (team == 0) {
+        prep_ph0();
+        for (int it = 0; it < iters; ++it) {
+            __syncthreads();  mfma_phase(0);
+            __syncthreads();  PP_STAMP(0); prep_ph1();
+            __syncthreads();  mfma_phase(1);
+            __syncthreads();  PP_STAMP(0); prep_ph0();
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            __syncthreads();  PP_STAMP(0); prep_ph0();
+            __syncthreads();  mfma_phase(0);
+            __syncthreads();  PP_STAMP(0); prep_ph1();
+            __syncthreads();  mfma_phase(1);
+        }
+    }
+    // drain, one team per interval (their read-add-writes must not overlap): team 0's deferred tile, then team 1's
+    // last chunk
+    __syncthreads();
+    if (team == 0 && deferred)
+        scatter_tiles(std::integral_constant<int, MTC - 1>{}, std::integral_constant<int, MTC>{}, x2, mq2);
+    __syncthreads();
+    if (team == 1 && pending) {
+        i32x4 mq[MTC];
+        load_row_words(mq);
+        scatter_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, MTC>{}, acc, mq);
+    }
+    (void)my_steps; (void)steps0;
+    __syncthreads();
+
+    // ---- fused tail: one wave per destination row, RB rows in flight -----------------------------------------
+    constexpr int CPL = D / 64;
+    float gm[CPL], bt[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        gm[c] = no_tail ? 1.f : gamma[lane * CPL + c];
+        bt[c] = no_tail ? 0.f : beta[lane * CPL + c];
+    }
+    constexpr int RB = 4;
+    for (int v0 = w; v0 < nrows; v0 += NWV * RB) {
+        float x[RB][CPL], inv[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int v = v0 + rb * NWV;
+            const int vc = v < nrows ? v : v0;
+            const int64_t node = node0 + vc;
+            const int deg = indeg[node];
+            inv[rb] = 1.0f / (float)(deg > 1 ? deg : 1);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + lane * CPL + c];
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int v = v0 + rb * NWV;
+            const int vc = v < nrows ? v : v0;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const float a = acc_lds[vc * D + lane * CPL + c] * inv[rb];
+                x[rb][c] = no_tail ? a : fmaxf(a + x[rb][c], 0.f);
+                s += x[rb][c];
+            }
+            if (!no_tail) {
+                const float mean = wave_sum(s) * (1.0f / D);
+                float var = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) { const float t = x[rb][c] - mean; var += t * t; }
+                const float rstd = 1.0f / sqrtf(wave_sum(var) * (1.0f / D) + eps);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) x[rb][c] = (x[rb][c] - mean) * rstd * gm[c] + bt[c];
+            }
+            if (v < nrows) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + v) * D + lane * CPL + c] = x[rb][c];
+            }
+        }
+    }
+#ifdef GHF_STAMPS
+    PP_STAMP(6);                                        // drain + tail
+    if (lane == 0 && blockIdx.x < 8192)
+        for (int i = 0; i < 8; ++i) ghf_pp_stamp_buf[((size_t)blockIdx.x * 8 + w) * 8 + i] = st_acc[i];
+#endif
+}
+
+template <int D>
+static int launch_pp_for(const MsgArgs& a, hipStream_t stream) {
+    using C = PpCfg<D>;
+    constexpr int CR = 16 * C::MTC;
+    constexpr size_t lds = (size_t)((C::BN + 4) * D + 2 * CR * D) * 4 + 2 * CR * 4;
+    GHF_REQUIRE(a.block_nodes == C::BN, "message(pp): plan block_nodes=%d, kernel for d=%d needs %d", a.block_nodes, D, C::BN);
+    GHF_REQUIRE(a.wlayout == GHF_WLAYOUT_FRAG16, "message(pp): weights must be in FRAG16 layout");
+    GHF_REQUIRE(a.chunk_tab && a.blk_chunk_off, "message(pp): the plan's chunk table is missing");
+    const int64_t row_end = a.row0 + a.rows;
+    GHF_REQUIRE(row_end == a.N || row_end % C::BN == 0, "message(pp): row range must end on a block boundary or at N");
+    if (a.rows <= 0) return GHF_OK;
+    GHF_REQUIRE((uint64_t)a.N * D * 4 < (1ull << 32) && (uint64_t)a.E * 4 < (1ull << 32) && (uint64_t)a.R * 2 * D * D * 4 < (1ull << 32),
+                "message(pp): 32-bit byte offsets need N*d*4, E*4 and R*2*d*d*4 below 4 GiB");
+    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_pp_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)cdiv(a.rows, C::BN);
+    message_pp_kernel<D><<<grid, 512, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.blk_chunk_off, a.indeg,
+                                                     a.R, a.W_msg, a.bias, a.ln_gamma, a.ln_beta, a.ln_eps, a.row0, row_end,
+                                                     a.h_out, (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int launch_message_pp(const MsgArgs& a, hipStream_t stream) {
+    if (a.d == 128) return launch_pp_for<128>(a, stream);
+    return set_err(GHF_EUNSUPPORTED, "message(pp): no ping-pong kernel for d=%d", a.d);
+}
+
+}  // namespace ghf
+
+#ifdef GHF_STAMPS
+extern "C" int ghf_debug_read_stamps_pp(unsigned long long* host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_pp_stamp_buf), count * sizeof(unsigned long long));
+}
+#endif

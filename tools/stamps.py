@@ -34,7 +34,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 nb = min(8192, -(-N // plan.block_nodes))
 buf = np.zeros(8192 * 8 * 8, dtype=np.uint64)
-fn = lib.ghf_debug_read_stamps
+lockstep = os.environ.get("GHF_KERNEL") == "lockstep" or d != 128
+fn = lib.ghf_debug_read_stamps if lockstep else lib.ghf_debug_read_stamps_pp
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.size) == 0
@@ -42,7 +43,10 @@ st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
 nw = d // 16
 st = st[:, :nw]
 tot = st.sum(axis=2)
-names = ["mem wait", "barrier", "prefetch issue", "compute", "scatter", "bookkeeping", "tail", "-"]
+if lockstep:
+    names = ["mem wait", "barrier", "prefetch issue", "compute", "scatter", "bookkeeping", "tail", "-"]
+else:   # ping-pong kernel (message_pp.hip)
+    names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: DMA issue"]
 print(f"blocks={nb} waves/block={nw} mean cycles per wave (100 MHz s_memtime ticks? see guide) = {tot.mean():.0f}")
-for i, n in enumerate(names[:7]):
-    print(f"  {n:22s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}")
+for i, n in enumerate(names[:8]):
+    print(f"  {n:22s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}   team0 {st[:, :4, i].mean():10.0f}  team1 {st[:, 4:, i].mean():10.0f}")
