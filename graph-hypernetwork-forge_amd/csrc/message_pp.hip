@@ -110,9 +110,6 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
     const int c_begin = __builtin_amdgcn_readfirstlane(blk_chunk_off[blk]);
     const int c_end = __builtin_amdgcn_readfirstlane(blk_chunk_off[blk + 1]);
     const int nchunks = c_end - c_begin;
-    const int my_chunks = (nchunks - team + 1) >> 1;   // chunks c_begin + team, + team + 2, ...
-    const int my_steps = 2 * my_chunks;                // a step = one K-phase of one of my chunks
-    const int steps0 = 2 * ((nchunks + 1) >> 1);       // team 0 never has fewer chunks than team 1
 
     auto load_desc = [&](int c) -> i32x2 {
         const int cc = (c < c_end ? c : c_begin) + vzero;               // clamp: a valid (ignored) entry
@@ -154,7 +151,7 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
         int v[IPW];
 #pragma unroll
         for (int i = 0; i < IPW; ++i) v[i] = __shfl(word, (tw * IPW + i) * RPI + lane / CPR, 64);
-        PP_STAMP(5);                                    // (diagnostic) row words + shuffles
+        PP_STAMP(5);                                    // prep: row words + shuffles
         const uint32_t nbase = ph == 0 ? 0u : (uint32_t)node0 - kbase;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
@@ -162,7 +159,7 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
             const uint32_t node = (ph == 0 ? (uint32_t)(v[i] & SRC_MASK) : (uint32_t)v[i]) + nbase;
             stg[i] = *at<f32x4>(h, node * (uint32_t)(D * 4) + (uint32_t)(((lane % CPR) ^ (rho & 15)) << 4));
         }
-        PP_STAMP(7);                                    // (diagnostic) gather issue
+        PP_STAMP(7);                                    // prep: gather issue
     };
     auto stage_commit = [&]() {
 #pragma unroll
@@ -405,7 +402,6 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
         load_row_words(mq);
         scatter_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, MTC>{}, acc, mq);
     }
-    (void)my_steps; (void)steps0;
     __syncthreads();
 
     // ---- fused tail: one wave per destination row, RB rows in flight -----------------------------------------

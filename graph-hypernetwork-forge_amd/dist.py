@@ -1,23 +1,30 @@
-"""Multi-GPU forward: one process per GPU, destination-range sharding, RCCL all-gather.
+"""Multi-GPU forward: one process per GPU, destination sharding, RCCL all-gather overlapped with compute.
 
-The path shards by DESTINATION node: rank g owns rows [g*S, (g+1)*S) (S a multiple of
-the kernel's destination-block size), i.e. every in-edge of its nodes.  Each edge is
-owned by exactly one rank, the per-destination sums never cross ranks, and the fused
-tail stays local; the one real exchange step per layer is making the new h visible
-everywhere: an in-place all-gather of [S, d] fp32 shards over xGMI (half the bytes of
-the all-reduce an edge-range partition would need — SURVEY.md §8e).  The input
-projection is sharded the same way.  Weight generation (0.5 GFLOP) is recomputed on
-every rank instead of broadcast.
+The path shards by DESTINATION node: a rank owns every in-edge of its rows, so each edge is
+owned by exactly one rank, the per-destination sums never cross ranks and the fused tail
+stays local.  The one real exchange step per layer is making the new h visible everywhere:
+an all-gather of fp32 rows over xGMI (half the bytes of the all-reduce an edge-range
+partition would need — SURVEY.md §8e).
 
-The compute steps are taken from an `ops` object so that the sharding/exchange logic
-can be exercised on CPU with gloo (tests/test_dist_gloo.py injects the oracle there);
-the product default, NativeOps, calls the HIP library and nothing else.
+Ownership is block-cyclic so that the exchange overlaps the compute: the (padded) rows are cut
+into C chunks of G*S rows, and inside chunk c rank g owns rows [(c*G+g)*S, (c*G+g+1)*S)
+(S a multiple of the kernel's destination-block size).  A layer then runs as
+    for c in chunks:  launch the message kernel on my rows of chunk c          (compute stream)
+                      all-gather chunk c in place: a contiguous [G*S, d] slice   (comm stream)
+so the gather of chunk c travels while chunk c+1 computes, and only the last chunk's gather
+is exposed.  The input projection is sharded the same way; weight generation (0.5 GFLOP) is
+recomputed on every rank instead of broadcast.
+
+The compute steps come from an `ops` object so that the sharding / exchange logic can be
+exercised on CPU with gloo (tests/test_dist_gloo.py injects the oracle there); the product
+default, NativeOps, calls the HIP library and nothing else.
 """
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -32,25 +39,32 @@ class ShardSpec:
     world: int
     rank: int
     block_nodes: int
-    S: int                      # rows per rank (multiple of block_nodes)
+    chunks: int                 # C
+    S: int                      # rows per (rank, chunk) slot; multiple of block_nodes
 
     @property
     def padded_rows(self) -> int:
-        return self.S * self.world
+        return self.S * self.world * self.chunks
 
-    @property
-    def lo(self) -> int:
-        return min(self.N, self.rank * self.S)
+    def slot(self, c: int, g: Optional[int] = None) -> Tuple[int, int]:
+        """Row range [lo, hi) (clipped to N) that rank g owns in chunk c."""
+        g = self.rank if g is None else g
+        lo = (c * self.world + g) * self.S
+        return min(self.N, lo), min(self.N, lo + self.S)
 
-    @property
-    def hi(self) -> int:
-        return min(self.N, (self.rank + 1) * self.S)
+    def chunk_rows(self, c: int) -> Tuple[int, int]:
+        """Padded row range of chunk c (all ranks' slots): what one all-gather fills."""
+        return c * self.world * self.S, (c + 1) * self.world * self.S
+
+    def owned(self) -> List[Tuple[int, int]]:
+        return [r for r in (self.slot(c) for c in range(self.chunks)) if r[1] > r[0]]
 
 
-def shard_spec(N: int, block_nodes: int, world: int, rank: int) -> ShardSpec:
+def shard_spec(N: int, block_nodes: int, world: int, rank: int, chunks: int = 1) -> ShardSpec:
     nb = -(-N // block_nodes)
-    S = -(-nb // world) * block_nodes
-    return ShardSpec(N=N, world=world, rank=rank, block_nodes=block_nodes, S=S)
+    chunks = max(1, min(chunks, -(-nb // world)))          # no more chunks than blocks per rank
+    S = -(-nb // (world * chunks)) * block_nodes
+    return ShardSpec(N=N, world=world, rank=rank, block_nodes=block_nodes, chunks=chunks, S=S)
 
 
 class NativeOps:
@@ -59,8 +73,8 @@ class NativeOps:
     def message_config(self, d: int):
         return _native.message_config(d)
 
-    def build_plan(self, edge_index, rel_ids, unique, N, d, device, row_range) -> GraphPlan:
-        return build_plan(edge_index, rel_ids, unique, N, d, device, row_range=row_range)
+    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner) -> GraphPlan:
+        return build_plan(edge_index, rel_ids, unique, N, d, device, owner=owner)
 
     def text_embs(self, model, unique: Sequence[str], device) -> torch.Tensor:
         return model.text_encoder(unique, device)
@@ -68,9 +82,12 @@ class NativeOps:
     def input_proj(self, model, x_rows: torch.Tensor, out_rows: torch.Tensor) -> None:
         _native.input_proj_fwd(x_rows, model.input_proj.weight.detach(), model.input_proj.bias.detach(), out=out_rows)
 
-    def layer(self, model, l: int, text_embs, h, plan, h_out, lo: int, hi: int) -> None:
-        gen, norm = model.weight_generators[l], model.layer_norms[l]
-        W, W_self, bias = gen.generate(text_embs, plan.wlayout)
+    def layer_weights(self, model, l: int, text_embs, plan):
+        return model.weight_generators[l].generate(text_embs, plan.wlayout)
+
+    def layer_rows(self, model, l: int, weights, h, plan, h_out, lo: int, hi: int) -> None:
+        norm = model.layer_norms[l]
+        W, W_self, bias = weights
         _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(), norm.bias.detach(),
                                   norm.eps, h_out, row0=lo, rows=hi - lo)
 
@@ -78,38 +95,66 @@ class NativeOps:
 class ShardedHyperGNN:
     """Runs ``HyperGNN.forward`` across the ranks of a process group; every rank returns the full [N, d]."""
 
-    def __init__(self, model, group: Optional[dist.ProcessGroup] = None, ops=None) -> None:
+    def __init__(self, model, group: Optional[dist.ProcessGroup] = None, ops=None, chunks: Optional[int] = None) -> None:
         self.model = model
         self.group = group
         self.ops = ops or NativeOps()
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.chunks = int(os.environ.get("GHF_DIST_CHUNKS", "4")) if chunks is None else chunks
         self._plan_key = None
         self._plan = None
         self._spec: Optional[ShardSpec] = None
+        self._comm_stream = None
 
-    def _exchange(self, buf: torch.Tensor, spec: ShardSpec) -> None:
-        """In-place all-gather: rank g contributes rows [g*S, (g+1)*S) of the padded buffer."""
-        if self.world == 1:
-            return
-        mine = buf[spec.rank * spec.S:(spec.rank + 1) * spec.S]
+    # -- exchange ---------------------------------------------------------------------------------------
+    def _gather_chunk(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
+        """In-place all-gather of chunk c: rank g contributes its slot of the contiguous chunk slice."""
+        lo, hi = spec.chunk_rows(c)
+        whole = buf[lo:hi]
+        mine = buf[lo + spec.rank * spec.S: lo + (spec.rank + 1) * spec.S]
         try:
-            dist.all_gather_into_tensor(buf, mine, group=self.group)
+            dist.all_gather_into_tensor(whole, mine, group=self.group)
         except (RuntimeError, NotImplementedError):          # backends without the fused form
-            parts = [buf[g * spec.S:(g + 1) * spec.S] for g in range(self.world)]
+            parts = [buf[lo + g * spec.S: lo + (g + 1) * spec.S] for g in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)
 
+    def _run_chunked(self, buf: torch.Tensor, spec: ShardSpec, compute_rows) -> None:
+        """compute_rows(lo, hi) fills my rows of a chunk; its gather overlaps the next chunk's compute."""
+        on_gpu = buf.is_cuda
+        if on_gpu:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=buf.device)
+            main = torch.cuda.current_stream(buf.device)
+            self._comm_stream.wait_stream(main)               # the previous users of `buf` are ordered before the gathers
+        for c in range(spec.chunks):
+            lo, hi = spec.slot(c)
+            if hi > lo:
+                compute_rows(lo, hi)
+            if on_gpu:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ready)
+                    self._gather_chunk(buf, spec, c)
+            else:
+                self._gather_chunk(buf, spec, c)
+        if on_gpu:
+            main.wait_stream(self._comm_stream)                # every row of `buf` is in place for the next layer
+
+    # -- plan -------------------------------------------------------------------------------------------
     def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], N: int, device) -> GraphPlan:
         key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, id(edge_texts), len(edge_texts), N)
         if key != self._plan_key:
             bn = self.ops.message_config(self.model.hidden_dim)[0]
-            spec = shard_spec(N, bn, self.world, self.rank)
+            spec = shard_spec(N, bn, self.world, self.rank, self.chunks)
             unique, ids = relation_ids(edge_texts)
             self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, self.model.hidden_dim,
-                                             device, (spec.lo, spec.hi))
+                                             device, (spec.S, self.world, self.rank))
             self._spec, self._plan_key, self._keep = spec, key, (edge_index, edge_texts)
         return self._plan
 
+    # -- forward ----------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, node_features: torch.Tensor, edge_index: torch.Tensor, edge_texts: List[str]) -> torch.Tensor:
         model = self.model
@@ -119,17 +164,15 @@ class ShardedHyperGNN:
         plan = self.plan_for(edge_index, edge_texts, N, device)
         spec = self._spec
         d = model.hidden_dim
-        h = torch.zeros(spec.padded_rows, d, dtype=torch.float32, device=device)
-        h_next = torch.zeros_like(h)
-        lo, hi = spec.lo, spec.hi
+        # fresh buffers per call (the result is a view of one of them); pad rows are exchanged but never read
+        h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
+        h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
-        if hi > lo:
-            self.ops.input_proj(model, node_features[lo:hi], h[lo:hi])
-        self._exchange(h, spec)
+        self._run_chunked(h, spec, lambda lo, hi: self.ops.input_proj(model, node_features[lo:hi], h[lo:hi]))
         for l in range(model.num_layers):
-            if hi > lo:
-                self.ops.layer(model, l, text_embs, h[:N], plan, h_next[:N], lo, hi)
-            self._exchange(h_next, spec)
+            weights = self.ops.layer_weights(model, l, text_embs, plan)
+            src, dst = h, h_next
+            self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], plan, dst[:N], lo, hi))
             h, h_next = h_next, h
         return h[:N]
 

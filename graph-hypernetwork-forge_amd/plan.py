@@ -56,8 +56,12 @@ class GraphPlan:
 
 def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: List[str], N: int, d: int,
                device: torch.device, force_generic: bool = False,
-               row_range: Optional[Tuple[int, int]] = None) -> GraphPlan:
-    """Run K0 on `device`.  Raises IndexError on out-of-range node or relation ids."""
+               row_range: Optional[Tuple[int, int]] = None,
+               owner: Optional[Tuple[int, int, int]] = None) -> GraphPlan:
+    """Run K0 on `device`.  Raises IndexError on out-of-range node or relation ids.
+
+    Multi-GPU shards keep only the in-edges of the rows they own: `row_range=(lo, hi)` for one contiguous range,
+    or `owner=(S, G, g)` for block-cyclic ownership (row v belongs to rank (v // S) % G)."""
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
     E = edge_index.size(1)
@@ -68,8 +72,12 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range
-    if row_range is not None:
-        keep = (ei[1] >= lo) & (ei[1] < hi)
+    if row_range is not None or owner is not None:
+        if owner is not None:
+            S, G, g = owner
+            keep = (torch.div(ei[1], S, rounding_mode="floor") % G) == g
+        else:
+            keep = (ei[1] >= lo) & (ei[1] < hi)
         ei = ei[:, keep].contiguous()
         rel = rel[keep].contiguous()
         if ei.size(1) == 0:                      # a shard without in-edges: empty plan, every row is "isolated"

@@ -31,11 +31,10 @@ class OracleOps:
     def message_config(self, d):
         return self.bn, 0, 48
 
-    def build_plan(self, edge_index, rel_ids, unique, N, d, device, row_range):
-        lo, hi = row_range
-        keep = (edge_index[1] >= lo) & (edge_index[1] < hi)          # a rank owns the in-edges of its rows
-        return SimpleNamespace(unique_texts=unique, ei=edge_index[:, keep], rel=rel_ids[keep], N=N,
-                               row_lo=lo, row_hi=hi, wlayout=0)
+    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner):
+        S, G, g = owner
+        keep = (edge_index[1] // S) % G == g                         # a rank owns the in-edges of its rows
+        return SimpleNamespace(unique_texts=unique, ei=edge_index[:, keep], rel=rel_ids[keep], N=N, wlayout=0)
 
     @staticmethod
     def _params(model):
@@ -47,10 +46,12 @@ class OracleOps:
     def input_proj(self, model, x_rows, out_rows):
         out_rows.copy_(torch.relu(x_rows @ model.input_proj.weight.t() + model.input_proj.bias))
 
-    def layer(self, model, l, text_embs, h, plan, h_out, lo, hi):
+    def layer_weights(self, model, l, text_embs, plan):
+        d = model.hidden_dim
+        return O.weight_generator(self._params(model), f"weight_generators.{l}.", text_embs, d, d)
+
+    def layer_rows(self, model, l, w, h, plan, h_out, lo, hi):
         p = self._params(model)
-        d = h.size(1)
-        w = O.weight_generator(p, f"weight_generators.{l}.", text_embs, d, d)
         agg = O.message_passing_factorised(h, plan.ei, plan.rel, w["W_msg"], w["W_self"], w["bias"])
         out = O.layer_tail(agg, h, p[f"layer_norms.{l}.weight"], p[f"layer_norms.{l}.bias"])
         h_out[lo:hi] = out[lo:hi]
@@ -62,7 +63,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, block_nodes, ret):
+def _worker(rank, world, port, case_name, block_nodes, chunks, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,7 +72,7 @@ def _worker(rank, world, port, case_name, block_nodes, ret):
         cfg = cases.MODELS[case.model]
         model = HyperGNN(cfg.text_dim, cfg.node_feat_dim, cfg.hidden_dim, cfg.num_layers).eval()
         model.load_state_dict({k: torch.from_numpy(v) for k, v in cfg.params().items()})
-        runner = ShardedHyperGNN(model, ops=OracleOps(block_nodes))
+        runner = ShardedHyperGNN(model, ops=OracleOps(block_nodes), chunks=chunks)
         x, ei = torch.from_numpy(case.node_features), torch.from_numpy(case.edge_index)
         out = runner(x, ei, case.edge_texts)
         out2 = runner(x, ei, case.edge_texts)                         # second call reuses the shard plan
@@ -83,12 +84,13 @@ def _worker(rank, world, port, case_name, block_nodes, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name,bn", [(2, "g3_mid32", 216), (3, "g3_mid32", 64), (2, "g2_toy", 8), (3, "g2_chain", 4)])
-def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn):
+@pytest.mark.parametrize("world,case_name,bn,chunks", [(2, "g3_mid32", 216, 4), (3, "g3_mid32", 64, 3), (2, "g3_mid32", 64, 1),
+                                                        (2, "g2_toy", 8, 4), (3, "g2_chain", 4, 2)])
+def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn, chunks):
     g = np.load(os.path.join(golden_dir, f"{case_name}.npz"))
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), case_name, bn, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case_name, bn, chunks, ret), nprocs=world, join=True)
     assert sorted(ret.keys()) == list(range(world))
     for r in range(world):
         assert_close(ret[r], g["out"], f"{case_name} world={world} rank={r}")
@@ -97,11 +99,19 @@ def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn):
 
 
 def test_shard_spec_covers_all_rows_once():
-    for N, bn, world in [(1_000_000, 216, 8), (1000, 216, 8), (5, 4, 3), (4_000_000, 88, 8), (217, 216, 2)]:
-        specs = [shard_spec(N, bn, world, r) for r in range(world)]
-        assert all(s.S % bn == 0 for s in specs) and specs[0].padded_rows >= N
+    for N, bn, world, chunks in [(1_000_000, 216, 8, 4), (1000, 216, 8, 4), (5, 4, 3, 2), (4_000_000, 88, 8, 1),
+                                 (217, 216, 2, 4), (100_000, 216, 4, 16)]:
+        specs = [shard_spec(N, bn, world, r, chunks) for r in range(world)]
+        s0 = specs[0]
+        assert s0.S % bn == 0 and s0.padded_rows >= N and 1 <= s0.chunks <= chunks
         covered = np.zeros(N, dtype=np.int32)
         for s in specs:
-            assert s.lo % bn == 0 or s.lo == N
-            covered[s.lo:s.hi] += 1
+            for lo, hi in s.owned():
+                assert lo % bn == 0
+                covered[lo:hi] += 1
+                owner = (np.arange(lo, hi) // s.S) % world
+                assert (owner == s.rank).all()                         # the plan's ownership rule
         assert (covered == 1).all()
+        for c in range(s0.chunks):                                      # a chunk's slots tile its all-gather slice
+            lo, hi = s0.chunk_rows(c)
+            assert hi - lo == world * s0.S

@@ -327,3 +327,32 @@ def test_full_size_c3_layer_properties():
     ref = O.message_passing_factorised(h, th(sub_ei), th(sub_rel), th(Wm), th(Ws), th(b))
     ref = O.layer_tail(ref, h, th(gamma), th(beta))[rows]
     assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), "sampled rows of the 10M-edge layer")
+
+
+# ---- the multi-GPU driver on one GPU: NCCL world of 1, 4 overlapped chunks ------------------------------
+
+def test_sharded_driver_single_rank_nccl(golden_dir):
+    """Exercises dist.ShardedHyperGNN's chunked launches, side-stream in-place all-gathers and plan ownership
+    filter on real hardware (world_size 1); the multi-rank logic is covered on CPU by tests/test_dist_gloo.py."""
+    import torch.distributed as dist
+    from graph_hypernetwork_forge_amd.dist import ShardedHyperGNN
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        for name in ("g6_c3", "g5_c2"):
+            (case,) = cases.graph_cases(only=[name])
+            g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+            model = make_model(cases.MODELS[case.model])
+            runner = ShardedHyperGNN(model, chunks=4)
+            x, ei = torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV)
+            out = runner(x, ei, case.edge_texts)
+            out2 = runner(x, ei, case.edge_texts)
+            torch.cuda.synchronize()
+            assert runner._spec.chunks == 4 and torch.equal(out, out2)
+            if "out" in g:
+                assert_close(out.cpu().numpy(), g["out"], f"sharded {name}")
+            else:
+                assert_close(out.cpu().numpy()[g["rows"]], g["out_rows"], f"sharded {name} rows")
+    finally:
+        dist.destroy_process_group()

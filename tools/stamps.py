@@ -46,7 +46,7 @@ tot = st.sum(axis=2)
 if lockstep:
     names = ["mem wait", "barrier", "prefetch issue", "compute", "scatter", "bookkeeping", "tail", "-"]
 else:   # ping-pong kernel (message_pp.hip)
-    names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: DMA issue"]
+    names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: gather issue"]
 print(f"blocks={nb} waves/block={nw} mean cycles per wave (100 MHz s_memtime ticks? see guide) = {tot.mean():.0f}")
 for i, n in enumerate(names[:8]):
     print(f"  {n:22s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}   team0 {st[:, :4, i].mean():10.0f}  team1 {st[:, 4:, i].mean():10.0f}")
