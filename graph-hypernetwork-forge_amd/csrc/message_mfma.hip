@@ -446,11 +446,11 @@ bool message_mfma_config(int d, int* block_nodes, int* chunk_rows) {
 }
 
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream) {
-    // d = 128 runs the ping-pong schedule (message_pp.hip); GHF_KERNEL=lockstep selects this file's kernel for A/B runs
+    // the ping-pong schedule (message_pp.hip) is the default; GHF_KERNEL=lockstep selects this file's kernel for A/B runs
     static const bool lockstep = getenv("GHF_KERNEL") && !strcmp(getenv("GHF_KERNEL"), "lockstep");
     switch (a.d) {
         case 128: return lockstep ? launch_for<128>(a, stream) : launch_message_pp(a, stream);
-        case 64:  return launch_for<64>(a, stream);
+        case 64:  return lockstep ? launch_for<64>(a, stream) : launch_message_pp(a, stream);
         default:  return set_err(GHF_EUNSUPPORTED, "message(mfma): no tuned kernel for d=%d", a.d);
     }
 }

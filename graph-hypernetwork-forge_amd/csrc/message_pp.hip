@@ -1,4 +1,4 @@
-// message_pp.hip — K2+K3, "ping-pong" schedule (hidden size 128).
+// message_pp.hip — K2+K3, "ping-pong" schedule (hidden sizes 128 and 64).
 //
 // Same math, plan, LDS layout and results as message_mfma.hip (see its header for the geometry: a workgroup owns
 // BN destination nodes and their fp32 sums in LDS; a chunk = <= 48 rows of one relation = a small GEMM run as two
@@ -60,12 +60,13 @@ __device__ unsigned long long ghf_pp_stamp_buf[8192 * 8 * 8];
 #endif
 
 template <int D> struct PpCfg;
-template <> struct PpCfg<128> { static constexpr int BN = 216, MTC = 3; };
+template <> struct PpCfg<128> { static constexpr int BN = 216, MTC = 3, WAVES_PER_SIMD = 2; };   // 162 KB LDS: 1 workgroup/CU
+template <> struct PpCfg<64>  { static constexpr int BN = 216, MTC = 3, WAVES_PER_SIMD = 4; };   //  81 KB LDS: 2 workgroups/CU
 
 struct PpChunk { int r; int e0; int rows; int cross; };     // rows == 0: none
 
 template <int D>
-__global__ __launch_bounds__(512) void message_pp_kernel(
+__global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kernel(
     const float* __restrict__ h, int64_t N, const uint32_t* __restrict__ sorted_key,
     const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
     const int32_t* __restrict__ blk_chunk_off, const int32_t* __restrict__ indeg, int R,
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
     constexpr int RPI = 256 / D;              // A rows per 1 KiB LDS-DMA wave-instruction
     constexpr int CR = 16 * MTC;              // rows per chunk
     constexpr int IPW = CR / RPI / TW;        // LDS-DMA instructions per wave per stage (6)
-    static_assert(NTW * TW == NT && CR % (RPI * TW) == 0 && MTC == 3, "bad tile config");
+    static_assert(NTW * TW == NT && (NTW == 1 || NTW == 2) && CR % (RPI * TW) == 0 && MTC == 3, "bad tile config");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc_lds = (float*)smem;                    // [BN + 4][D]: block sums + 4 dummy rows
@@ -249,10 +250,13 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[t][s]) : "v"(addr[s]), "n"(t * 64) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]),
-                           "+v"(v[NTW - 1][0]), "+v"(v[NTW - 1][1]), "+v"(v[NTW - 1][2]), "+v"(v[NTW - 1][3])
-                         :: "memory");
+            if constexpr (NTW == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]),
+                               "+v"(v[NTW - 1][0]), "+v"(v[NTW - 1][1]), "+v"(v[NTW - 1][2]), "+v"(v[NTW - 1][3])
+                             :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]) :: "memory");
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
 #pragma unroll
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(512) void message_pp_kernel(
     PpChunk ch_next{0, 0, 0, 0};
     i32x2 d_next = load_desc(kc + 2);
     Words wd{0, 0}, wd_next{0, 0};                     // plan words of `ch` / of my next chunk
-    float bias_v[NTW] = {0.f, 0.f};
+    float bias_v[NTW] = {};
     int pending = 0;                                   // live row tiles of my finished, not yet scattered chunk
 
     // The scatter of a finished chunk is split over my next two PREPs so that neither exceeds the partner's MFMA
@@ -482,6 +486,7 @@ static int launch_pp_for(const MsgArgs& a, hipStream_t stream) {
 
 int launch_message_pp(const MsgArgs& a, hipStream_t stream) {
     if (a.d == 128) return launch_pp_for<128>(a, stream);
+    if (a.d == 64) return launch_pp_for<64>(a, stream);
     return set_err(GHF_EUNSUPPORTED, "message(pp): no ping-pong kernel for d=%d", a.d);
 }
 
