@@ -36,10 +36,21 @@ constexpr int WAVE = 64;
 constexpr uint32_t KEY_INVALID = 0xFFFFFFFFu;
 
 // ---- wave / block reductions (64-lane wavefronts) --------------------------------
+// Sum over the 64 lanes, result in every lane.  Data-parallel-primitive moves only (no LDS crossbar):
+// butterfly inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 fold the four rows into lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {
+    // value of the lane selected by CTRL for rows enabled in ROW_MASK, 0 elsewhere
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_take<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);      // row_half_mirror
+    v += dpp_take<0x140, 0xF>(v);      // row_mirror: every lane of a row holds the row's sum
+    v += dpp_take<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Sum over a block of NWAVES*64 threads; `red` is >= NWAVES floats of LDS.
