@@ -29,6 +29,7 @@ namespace ghf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int PP_WAIT_VMCNT0 = 0x0F70;      // s_waitcnt vmcnt(0) only (builtin form: modelled by hipcc)
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
     auto scatter_tiles = [&](auto M0tag, auto M1tag, f32x4 (&x)[MTC][NTW], const i32x4 (&mq)[MTC]) {
         constexpr int M0 = decltype(M0tag)::value, M1 = decltype(M1tag)::value;
         f32x4 y[MTC][NTW];
-        const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16);
+        const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16 * NTW);   // NTW == 2: interleaved
 #pragma unroll
         for (int m = M0; m < M1; ++m)
 #pragma unroll
@@ -238,30 +239,32 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
                     y[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, x[m][t][s], y[m][t], 0, 0, 0);
             }
         // plain LDS read-add-write through inline asm (see message_mfma.hip), tile by tile: a run of equal
-        // destinations may continue into the next tile, and 8 loads per tile keep the LDS pipe busy anyway
+        // destinations may continue into the next tile.  With two fragments per wave (D = 128) the block sums keep a
+        // wave's 32 columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column 32*tw + 16*t + c16; the tail
+        // undoes it), so a lane's two values are adjacent and move with one 64-bit LDS access.
 #pragma unroll
         for (int m = M0; m < M1; ++m) {
-            float v[NTW][4];
             unsigned addr[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) addr[s] = strip + ((unsigned)mq[m][s] & ~15u);           // the run's target row, or a dummy
+            if constexpr (NTW == 2) {
+                f32x2 v[4];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
+                for (int s = 0; s < 4; ++s) asm volatile("ds_read_b64 %0, %1" : "=v"(v[s]) : "v"(addr[s]) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[t][s]) : "v"(addr[s]), "n"(t * 64) : "memory");
-            if constexpr (NTW == 2)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]),
-                               "+v"(v[NTW - 1][0]), "+v"(v[NTW - 1][1]), "+v"(v[NTW - 1][2]), "+v"(v[NTW - 1][3])
-                             :: "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]) :: "memory");
+                for (int s = 0; s < 4; ++s) {
+                    const f32x2 r = v[s] + (f32x2){y[m][0][s], y[m][1][s]};
+                    asm volatile("ds_write_b64 %0, %1" :: "v"(addr[s]), "v"(r) : "memory");
+                }
+            } else {
+                float v[4];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
+                for (int s = 0; s < 4; ++s) asm volatile("ds_read_b32 %0, %1" : "=v"(v[s]) : "v"(addr[s]) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr[s]), "v"(v[t][s] + y[m][t][s]), "n"(t * 64) : "memory");
+                for (int s = 0; s < 4; ++s) asm volatile("ds_write_b32 %0, %1" :: "v"(addr[s]), "v"(v[s] + y[m][0][s]) : "memory");
+            }
         }
     };
     auto load_row_words = [&](i32x4 (&mq)[MTC]) {
@@ -410,11 +413,16 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
 
     // ---- fused tail: one wave per destination row, RB rows in flight -----------------------------------------
     constexpr int CPL = D / 64;
+    // LDS position lane*CPL + c of a row of the sums holds output column col[c] (see the scatter): for D = 128 the
+    // lane's two positions are columns o and o + 16, for D = 64 position = column.
+    int col[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) col[c] = NTW == 2 ? 32 * (lane >> 4) + 16 * c + (lane & 15) : lane * CPL + c;
     float gm[CPL], bt[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        gm[c] = no_tail ? 1.f : gamma[lane * CPL + c];
-        bt[c] = no_tail ? 0.f : beta[lane * CPL + c];
+        gm[c] = no_tail ? 1.f : gamma[col[c]];
+        bt[c] = no_tail ? 0.f : beta[col[c]];
     }
     constexpr int RB = 4;
     for (int v0 = w; v0 < nrows; v0 += NWV * RB) {
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
             const int deg = indeg[node];
             inv[rb] = 1.0f / (float)(deg > 1 ? deg : 1);
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + lane * CPL + c];
+            for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + col[c]];
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
             }
             if (v < nrows) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + v) * D + lane * CPL + c] = x[rb][c];
+                for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + v) * D + col[c]] = x[rb][c];
             }
         }
     }
