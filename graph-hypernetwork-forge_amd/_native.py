@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GHF_FLAG_NO_TAIL = 1
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
@@ -32,14 +32,17 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size
 SIGNATURES = {
     "ghf_abi_version": (_i32, []),
     "ghf_last_error": (C.c_char_p, []),
-    "ghf_message_config": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "ghf_message_config": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ghf_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "ghf_plan_max_chunks": (_i64, [_i64, _i64, _i32, _i32, _i32]),
-    "ghf_plan_build": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ghf_plan_max_items": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    "ghf_plan_build": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp]),
     "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                  _vp, _vp, _vp, _vp]),
     "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "ghf_message_layer_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32,
+    "ghf_message_layer_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
+                                     _vp, _vp, _vp, _i32,
                                      _vp, _vp, _f32, _i64, _i64, _vp, _i32, _vp]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
 }
@@ -115,15 +118,16 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
 # thin wrappers (tensors in, tensors out; all work enqueued on the current stream)
 # ---------------------------------------------------------------------------
 
-def message_config(d: int) -> Tuple[int, int, int]:
-    """(block_nodes, weight layout, chunk_rows) of the message kernel for hidden size d."""
-    bn, wl, cr = _i32(0), _i32(0), _i32(0)
-    _check(load().ghf_message_config(int(d), C.byref(bn), C.byref(wl), C.byref(cr)), "ghf_message_config")
-    return bn.value, wl.value, cr.value
+def message_config(d: int) -> Tuple[int, int, int, int]:
+    """(block_nodes, weight layout, chunk_rows, split_chunks) of the message kernel for hidden size d."""
+    bn, wl, cr, sc = _i32(0), _i32(0), _i32(0), _i32(0)
+    _check(load().ghf_message_config(int(d), C.byref(bn), C.byref(wl), C.byref(cr), C.byref(sc)), "ghf_message_config")
+    return bn.value, wl.value, cr.value, sc.value
 
 
-def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, block_nodes: int, chunk_rows: int = 0):
-    """Returns (sorted_key [uint32 bits in int32], sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, status)."""
+def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, block_nodes: int, chunk_rows: int = 0,
+               split_chunks: int = 0):
+    """Returns a dict of the plan's device arrays (names as in include/ghf.h: ghf_plan_build) plus `status` [3]."""
     lib = load()
     ei = _req(edge_index, torch.int64, "edge_index")
     rel = _req(rel_id, torch.int64, "rel_id")
@@ -133,20 +137,21 @@ def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, b
     nseg = N if block_nodes == 1 else nb * R
     ws_bytes = lib.ghf_plan_workspace_bytes(N, E, R, block_nodes, chunk_rows)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    skey = torch.empty(E, dtype=torch.int32, device=dev)      # holds uint32 bit patterns
-    ssrc = torch.empty(E, dtype=torch.int32, device=dev)
-    seg_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
-    indeg = torch.empty(N, dtype=torch.int32, device=dev)
-    status = torch.empty(1, dtype=torch.int32, device=dev)
-    chunk_tab = blk_chunk_off = None
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)       # noqa: E731
+    out = dict(sorted_key=i32(E), sorted_src=i32(E), seg_off=i32(nseg + 1), indeg=i32(N), status=i32(3),
+               chunk_tab=None, blk_chunk_off=None, item_tab=None, blk_item_off=None)   # sorted_key: uint32 bit patterns
     if block_nodes > 1:
-        max_chunks = lib.ghf_plan_max_chunks(N, E, R, block_nodes, chunk_rows)
-        chunk_tab = torch.zeros(2 * max_chunks, dtype=torch.int32, device=dev)
-        blk_chunk_off = torch.empty(nb + 1, dtype=torch.int32, device=dev)
-    _check(lib.ghf_plan_build(_ptr(ei), _ptr(rel), N, E, R, block_nodes, chunk_rows, _ptr(ws), ws_bytes, _ptr(skey),
-                              _ptr(ssrc), _ptr(seg_off), _ptr(indeg), _ptr(chunk_tab), _ptr(blk_chunk_off),
-                              _ptr(status), _stream()), "ghf_plan_build")
-    return skey, ssrc, seg_off, indeg, chunk_tab, blk_chunk_off, status
+        out["chunk_tab"] = torch.zeros(2 * lib.ghf_plan_max_chunks(N, E, R, block_nodes, chunk_rows), dtype=torch.int32,
+                                       device=dev)
+        out["blk_chunk_off"] = i32(nb + 1)
+        out["item_tab"] = torch.zeros(4 * lib.ghf_plan_max_items(N, E, R, block_nodes, chunk_rows, split_chunks),
+                                      dtype=torch.int32, device=dev)
+        out["blk_item_off"] = i32(nb + 1)
+    _check(lib.ghf_plan_build(_ptr(ei), _ptr(rel), N, E, R, block_nodes, chunk_rows, split_chunks, _ptr(ws), ws_bytes,
+                              _ptr(out["sorted_key"]), _ptr(out["sorted_src"]), _ptr(out["seg_off"]), _ptr(out["indeg"]),
+                              _ptr(out["chunk_tab"]), _ptr(out["blk_chunk_off"]), _ptr(out["item_tab"]),
+                              _ptr(out["blk_item_off"]), _ptr(out["status"]), _stream()), "ghf_plan_build")
+    return out
 
 
 def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], log_scales: torch.Tensor,
@@ -195,16 +200,19 @@ def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Option
                       bias: torch.Tensor, wlayout: int, ln_gamma: Optional[torch.Tensor],
                       ln_beta: Optional[torch.Tensor], ln_eps: float, h_out: torch.Tensor,
                       row0: int = 0, rows: Optional[int] = None, flags: int = 0) -> torch.Tensor:
-    """`plan` is any object with sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, N, E, R, block_nodes."""
+    """`plan` is a plan.GraphPlan: the device arrays, the host copy of the item offsets and the split-block scratch."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
     if rows is None:
         rows = N - row0
+    item0, n_items, partial = plan.items_for(row0, rows, d)
     _check(lib.ghf_message_layer_fwd(_ptr(h), N, d, _ptr(plan.sorted_key), _ptr(plan.sorted_src), _ptr(plan.seg_off),
-                                     _ptr(plan.indeg), _ptr(plan.chunk_tab), _ptr(plan.blk_chunk_off), plan.E, plan.R, plan.block_nodes, _ptr(W_msg), _ptr(W_self),
-                                     _ptr(bias), wlayout, _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows,
-                                     _ptr(h_out), flags, _stream()), "ghf_message_layer_fwd")
+                                     _ptr(plan.indeg), _ptr(plan.chunk_tab), _ptr(plan.blk_chunk_off), _ptr(plan.item_tab),
+                                     _ptr(plan.blk_item_off), item0, n_items, _ptr(partial), plan.E, plan.R,
+                                     plan.block_nodes, _ptr(W_msg), _ptr(W_self), _ptr(bias), wlayout, _ptr(ln_gamma),
+                                     _ptr(ln_beta), float(ln_eps), row0, rows, _ptr(h_out), flags, _stream()),
+           "ghf_message_layer_fwd")
     return h_out
 
 

@@ -28,19 +28,25 @@ int ghf_abi_version(void) { return GHF_ABI_VERSION; }
 
 const char* ghf_last_error(void) { return err_buf(); }
 
-int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows) {
-    if (!block_nodes || !wlayout || !chunk_rows) return set_err(GHF_EINVAL, "message_config: null output pointer");
-    int bn = 1, cr = 0;
-    if (message_mfma_config(d, &bn, &cr)) {
+int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks) {
+    if (!block_nodes || !wlayout || !chunk_rows || !split_chunks) return set_err(GHF_EINVAL, "message_config: null output pointer");
+    int bn = 1, cr = 0, sc = 0;
+    if (message_mfma_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_FRAG16;
         *chunk_rows = cr;
+        *split_chunks = sc;
     } else {
         *block_nodes = 1;
         *wlayout = GHF_WLAYOUT_NATURAL;
         *chunk_rows = 0;
+        *split_chunks = 0;
     }
     return GHF_OK;
+}
+
+int64_t ghf_plan_max_items(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows, int split_chunks) {
+    return plan_max_items(N, E, R, block_nodes, chunk_rows, split_chunks);
 }
 
 size_t ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows) {
@@ -52,15 +58,16 @@ int64_t ghf_plan_max_chunks(int64_t N, int64_t E, int R, int block_nodes, int ch
 }
 
 int ghf_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, int64_t E, int R, int block_nodes,
-                   int chunk_rows, void* workspace, size_t workspace_bytes, uint32_t* sorted_key, int32_t* sorted_src,
-                   int32_t* seg_off, int32_t* indeg, int32_t* chunk_tab, int32_t* blk_chunk_off, int32_t* status,
-                   void* stream) {
+                   int chunk_rows, int split_chunks, void* workspace, size_t workspace_bytes, uint32_t* sorted_key,
+                   int32_t* sorted_src, int32_t* seg_off, int32_t* indeg, int32_t* chunk_tab, int32_t* blk_chunk_off,
+                   int32_t* item_tab, int32_t* blk_item_off, int32_t* status, void* stream) {
     GHF_REQUIRE(edge_index && rel_id && workspace && sorted_key && sorted_src && seg_off && indeg && status,
                 "plan_build: null pointer argument");
     GHF_REQUIRE(block_nodes == 1 || (chunk_tab && blk_chunk_off && chunk_rows > 0),
                 "plan_build: block plans need chunk_tab, blk_chunk_off and chunk_rows");
-    return launch_plan_build(edge_index, rel_id, N, E, R, block_nodes, chunk_rows, workspace, workspace_bytes, sorted_key,
-                             sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, status, (hipStream_t)stream);
+    return launch_plan_build(edge_index, rel_id, N, E, R, block_nodes, chunk_rows, split_chunks, workspace, workspace_bytes,
+                             sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, status,
+                             (hipStream_t)stream);
 }
 
 int ghf_weightgen_fwd(const float* text_emb, const float* const* head_params, const float* log_scales,
@@ -80,7 +87,8 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in, int
 
 int ghf_message_layer_fwd(const float* h, int64_t N, int d, const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg, const int32_t* chunk_tab,
-                          const int32_t* blk_chunk_off, int64_t E, int R, int block_nodes,
+                          const int32_t* blk_chunk_off, const int32_t* item_tab, const int32_t* blk_item_off,
+                          int64_t item0, int64_t n_items, float* partial, int64_t E, int R, int block_nodes,
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0, int64_t rows,
                           float* h_out, int flags, void* stream) {
@@ -92,8 +100,10 @@ int ghf_message_layer_fwd(const float* h, int64_t N, int d, const uint32_t* sort
     GHF_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= N, "message_layer_fwd: row range [%lld,+%lld) outside [0,%lld)",
                 (long long)row0, (long long)rows, (long long)N);
     GHF_REQUIRE(row0 % block_nodes == 0, "message_layer_fwd: row0 must be a multiple of block_nodes");
-    GHF_REQUIRE(block_nodes == 1 || (chunk_tab && blk_chunk_off), "message_layer_fwd: block plans need the chunk table");
-    MsgArgs a{h, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, E, R, block_nodes, W_msg, W_self, bias, wlayout,
+    GHF_REQUIRE(block_nodes == 1 || (chunk_tab && blk_chunk_off && item_tab && blk_item_off && item0 >= 0 && n_items >= 0),
+                "message_layer_fwd: block plans need the chunk and item tables");
+    MsgArgs a{h, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, item0, n_items,
+              partial, E, R, block_nodes, W_msg, W_self, bias, wlayout,
               ln_gamma, ln_beta, ln_eps, row0, rows, h_out, flags};
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
     return launch_message_mfma(a, (hipStream_t)stream);

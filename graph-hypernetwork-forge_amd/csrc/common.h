@@ -71,11 +71,13 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // Launchers (one per translation unit), called from capi.hip.
 int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, int64_t E, int R,
-                      int block_nodes, int chunk_rows, void* ws, size_t ws_bytes, uint32_t* sorted_key,
-                      int32_t* sorted_src, int32_t* seg_off, int32_t* indeg, int32_t* chunk_tab,
-                      int32_t* blk_chunk_off, int32_t* status, hipStream_t stream);
+                      int block_nodes, int chunk_rows, int split_chunks, void* ws, size_t ws_bytes,
+                      uint32_t* sorted_key, int32_t* sorted_src, int32_t* seg_off, int32_t* indeg,
+                      int32_t* chunk_tab, int32_t* blk_chunk_off, int32_t* item_tab, int32_t* blk_item_off,
+                      int32_t* status, hipStream_t stream);
 size_t plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
 int64_t plan_max_chunks(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
+int64_t plan_max_items(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows, int split_chunks);
 constexpr int SRC_BITS = 28;                          // sorted_src: node id in bits 0..27, run head in 28..31
 constexpr int32_t SRC_MASK = (1 << SRC_BITS) - 1;
 
@@ -90,6 +92,7 @@ struct MsgArgs {
     const float* h; int64_t N; int d;
     const uint32_t* sorted_key; const int32_t* sorted_src; const int32_t* seg_off; const int32_t* indeg;
     const int32_t* chunk_tab; const int32_t* blk_chunk_off;
+    const int32_t* item_tab; const int32_t* blk_item_off; int64_t item0; int64_t n_items; float* partial;
     int64_t E; int R; int block_nodes;
     const float* W_msg; const float* W_self; const float* bias; int wlayout;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
@@ -98,7 +101,8 @@ struct MsgArgs {
 int launch_message_generic(const MsgArgs& a, hipStream_t stream);
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
 int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)
-bool message_mfma_config(int d, int* block_nodes, int* chunk_rows);
+bool message_mfma_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
+int launch_combine_split(const MsgArgs& a, hipStream_t stream);     // sums the partial slots of split blocks + tail
 
 int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,
                 int64_t row0, int64_t rows, int d, float* h_out, hipStream_t stream);

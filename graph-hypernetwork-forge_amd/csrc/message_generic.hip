@@ -123,6 +123,71 @@ __global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__
     tail_store<GEN_TPB / 64>(x, d, red, g, b, eps, h_out + (size_t)v * d);
 }
 
+// Second stage for split destination blocks (hubs): sum the block's partial slots in item order (fixed order:
+// reproducible), then the K3 tail.  One workgroup per block of the row range; blocks with a single item return at
+// once.  One wave per destination row, lanes stride the columns.
+constexpr int COMB_MAX_PER_LANE = GEN_MAX_D / 64;
+__global__ __launch_bounds__(256) void combine_split_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off,
+    const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
+    const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int64_t row_end,
+    float* __restrict__ h_out, int no_tail) {
+    const int64_t blk = blk0 + blockIdx.x;
+    const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
+    if (i1 - i0 <= 1) return;
+    const int slot0 = item_tab[4 * (size_t)i0 + 3], nslots = i1 - i0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t node0 = blk * BN;
+    const int nrows = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
+    for (int v = w; v < nrows; v += 4) {
+        const int64_t node = node0 + v;
+        const int deg = indeg[node];
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        float x[COMB_MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
+            const int o = lane + 64 * c;
+            x[c] = 0.f;
+            if (o < d) {
+                float t = 0.f;
+                for (int j = 0; j < nslots; ++j) t += partial[((size_t)(slot0 + j) * BN + v) * d + o];
+                t *= inv;
+                x[c] = no_tail ? t : fmaxf(t + h[(size_t)node * d + o], 0.f);
+                s += x[c];
+            }
+        }
+        if (!no_tail) {
+            const float mean = wave_sum(s) / (float)d;
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < COMB_MAX_PER_LANE; ++c)
+                if (lane + 64 * c < d) { const float t = x[c] - mean; var += t * t; }
+            const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
+#pragma unroll
+            for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
+                const int o = lane + 64 * c;
+                if (o < d) x[c] = (x[c] - mean) * rstd * g[o] + b[o];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
+            const int o = lane + 64 * c;
+            if (o < d) h_out[(size_t)node * d + o] = x[c];
+        }
+    }
+}
+
+int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
+    const int64_t blk0 = a.row0 / a.block_nodes, row_end = a.row0 + a.rows;
+    const unsigned grid = (unsigned)cdiv(a.rows, a.block_nodes);
+    combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
+                                                   a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out,
+                                                   (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 int launch_message_generic(const MsgArgs& a, hipStream_t stream) {
     GHF_REQUIRE(a.block_nodes == 1, "message(generic): plan must be CSR (block_nodes == 1), got %d", a.block_nodes);
     GHF_REQUIRE(a.wlayout == GHF_WLAYOUT_NATURAL && a.W_self, "message(generic): needs NATURAL weights");

@@ -437,7 +437,12 @@ static int launch_for(const MsgArgs& a, hipStream_t stream) {
     return GHF_OK;
 }
 
-bool message_mfma_config(int d, int* block_nodes, int* chunk_rows) {
+// split_chunks: a destination block with more chunks than this is cut into several work items (plan.hip).  A block of a
+// uniform graph at the BASELINE configs has ~65 chunks, so only real hubs are split.
+constexpr int SPLIT_CHUNKS = 128;
+
+bool message_mfma_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks) {
+    *split_chunks = SPLIT_CHUNKS;
     switch (d) {
         case 128: *block_nodes = MfmaCfg<128>::BN; *chunk_rows = 16 * MfmaCfg<128>::MTC; return true;
         case 64:  *block_nodes = MfmaCfg<64>::BN;  *chunk_rows = 16 * MfmaCfg<64>::MTC;  return true;

@@ -70,7 +70,8 @@ template <int D>
 __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kernel(
     const float* __restrict__ h, int64_t N, const uint32_t* __restrict__ sorted_key,
     const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
-    const int32_t* __restrict__ blk_chunk_off, const int32_t* __restrict__ indeg, int R,
+    const int32_t* __restrict__ item_tab, int64_t item0, float* __restrict__ partial,
+    const int32_t* __restrict__ indeg, int R,
     const float* __restrict__ Wfrag, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int64_t row0, int64_t row_end, float* __restrict__ h_out, int no_tail) {
@@ -96,7 +97,11 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = w >> 2, tw = w & 3;              // waves w and w+4 share a SIMD: one of each team per SIMD
     const int q = lane >> 4, c16 = lane & 15;
-    const int64_t blk = row0 / BN + blockIdx.x;
+    // work item: { block, first chunk, one past last chunk, scratch slot or -1 } (plan.hip); a heavy block (the hub
+    // of a power-law graph) is several items, whose raw sums go to scratch slots and are combined by a second kernel
+    const i32x4 item = *(const i32x4*)(item_tab + 4 * (size_t)(item0 + blockIdx.x));
+    const int64_t blk = __builtin_amdgcn_readfirstlane(item[0]);
+    const int slot = __builtin_amdgcn_readfirstlane(item[3]);
     const int64_t node0 = blk * BN;
     const int nrows = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
     const uint32_t seg0 = (uint32_t)(blk * R);
@@ -109,8 +114,8 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
     PP_STAMP_DECL;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));    // opaque 0: keeps the descriptor loads on the vector path
-    const int c_begin = __builtin_amdgcn_readfirstlane(blk_chunk_off[blk]);
-    const int c_end = __builtin_amdgcn_readfirstlane(blk_chunk_off[blk + 1]);
+    const int c_begin = __builtin_amdgcn_readfirstlane(item[1]);
+    const int c_end = __builtin_amdgcn_readfirstlane(item[2]);
     const int nchunks = c_end - c_begin;
 
     auto load_desc = [&](int c) -> i32x2 {
@@ -424,6 +429,13 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
         gm[c] = no_tail ? 1.f : gamma[col[c]];
         bt[c] = no_tail ? 0.f : beta[col[c]];
     }
+    if (slot >= 0) {                                   // one item of a split block: raw sums (column order) to my slot
+        float* __restrict__ ps = partial + (size_t)slot * BN * D;
+        for (int v = w; v < BN; v += NWV)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) ps[(size_t)v * D + col[c]] = acc_lds[v * D + lane * CPL + c];
+        return;
+    }
     constexpr int RB = 4;
     for (int v0 = w; v0 < nrows; v0 += NWV * RB) {
         float x[RB][CPL], inv[RB];
@@ -477,18 +489,21 @@ static int launch_pp_for(const MsgArgs& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)((C::BN + 4) * D + 2 * CR * D) * 4 + 2 * CR * 4;
     GHF_REQUIRE(a.block_nodes == C::BN, "message(pp): plan block_nodes=%d, kernel for d=%d needs %d", a.block_nodes, D, C::BN);
     GHF_REQUIRE(a.wlayout == GHF_WLAYOUT_FRAG16, "message(pp): weights must be in FRAG16 layout");
-    GHF_REQUIRE(a.chunk_tab && a.blk_chunk_off, "message(pp): the plan's chunk table is missing");
+    GHF_REQUIRE(a.chunk_tab && a.item_tab && a.blk_item_off, "message(pp): the plan's chunk / item tables are missing");
     const int64_t row_end = a.row0 + a.rows;
     GHF_REQUIRE(row_end == a.N || row_end % C::BN == 0, "message(pp): row range must end on a block boundary or at N");
     if (a.rows <= 0) return GHF_OK;
     GHF_REQUIRE((uint64_t)a.N * D * 4 < (1ull << 32) && (uint64_t)a.E * 4 < (1ull << 32) && (uint64_t)a.R * 2 * D * D * 4 < (1ull << 32),
                 "message(pp): 32-bit byte offsets need N*d*4, E*4 and R*2*d*d*4 below 4 GiB");
     GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_pp_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)cdiv(a.rows, C::BN);
-    message_pp_kernel<D><<<grid, 512, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.blk_chunk_off, a.indeg,
-                                                     a.R, a.W_msg, a.bias, a.ln_gamma, a.ln_beta, a.ln_eps, a.row0, row_end,
-                                                     a.h_out, (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+    GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(pp): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
+    GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(pp): split blocks need the `partial` scratch");
+    message_pp_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
+                                                                   a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
+                                                                   a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out,
+                                                                   (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
     GHF_LAUNCH_CHECK();
+    if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
     return GHF_OK;
 }
 

@@ -11,7 +11,11 @@
 // every wave of every chunk are done here once per graph:
 //  - the chunk table: each group cut into chunks of <= chunk_rows edges, listed per block;
 //  - each edge's "run head": the first row of its run of equal destinations inside its
-//    16-row tile, packed into bits 28..31 of sorted_src (the kernel's segment-sum selector).
+//    16-row tile, packed into bits 28..31 of sorted_src (the kernel's segment-sum selector);
+//  - work items: a destination block with more than `split_chunks` chunks (a hub of a power-law
+//    graph) is cut into several items, each a contiguous range of its chunks, so that no
+//    workgroup walks more than ~split_chunks chunks; a split block's items write partial sums
+//    to scratch slots and are combined by a second kernel.
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -109,6 +113,41 @@ __global__ void plan_heads_kernel(const uint32_t* __restrict__ sorted_key, const
     sorted_src[e] = (int32_t)(((uint32_t)sorted_src[e] & (uint32_t)SRC_MASK) | ((uint32_t)head << SRC_BITS));
 }
 
+// items per block: 1, or ceil(chunks / T) for a heavy block; slots = items of split blocks only
+__global__ void plan_item_count_kernel(const int32_t* __restrict__ blk_chunk_off, int64_t NB, int T,
+                                       int32_t* __restrict__ ni, int32_t* __restrict__ nslot) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB) return;
+    const int n = blk_chunk_off[b + 1] - blk_chunk_off[b];
+    const int k = n > T ? (n + T - 1) / T : 1;
+    ni[b] = k;
+    nslot[b] = k > 1 ? k : 0;
+}
+
+// item_tab[i] = { block, first chunk, one past last chunk, scratch slot or -1 }; blk_item_off = exclusive scan of ni
+__global__ void plan_item_fill_kernel(const int32_t* __restrict__ blk_chunk_off, const int32_t* __restrict__ ni,
+                                      const int32_t* __restrict__ ioff, const int32_t* __restrict__ soff, int64_t NB,
+                                      int32_t* __restrict__ item_tab, int32_t* __restrict__ blk_item_off,
+                                      int32_t* __restrict__ counts) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > NB) return;
+    if (b == NB) {                                       // totals: items, scratch slots
+        const int items = ioff[NB - 1] + ni[NB - 1];
+        blk_item_off[NB] = items;
+        counts[0] = items;
+        counts[1] = soff[NB - 1] + (ni[NB - 1] > 1 ? ni[NB - 1] : 0);
+        return;
+    }
+    const int c0 = blk_chunk_off[b], n = blk_chunk_off[b + 1] - c0, k = ni[b];
+    const int per = (n + k - 1) / k;
+    blk_item_off[b] = ioff[b];
+    for (int j = 0; j < k; ++j) {
+        int32_t* it = item_tab + 4 * (size_t)(ioff[b] + j);
+        const int a = c0 + j * per, z = c0 + ((j + 1) * per < n ? (j + 1) * per : n);
+        it[0] = (int32_t)b; it[1] = a < z ? a : z; it[2] = z; it[3] = k > 1 ? soff[b] + j : -1;
+    }
+}
+
 static size_t sort_temp_bytes(int64_t E) {
     size_t tb = 0;
     hipcub::DeviceRadixSort::SortPairs<uint32_t, int32_t>(nullptr, tb, nullptr, nullptr, nullptr, nullptr,
@@ -124,6 +163,11 @@ static size_t scan_temp_bytes(int64_t n) {
 
 static int64_t num_segments(int64_t N, int R, int BN) { return BN == 1 ? N : cdiv(N, BN) * R; }
 
+int64_t plan_max_items(int64_t N, int64_t E, int R, int BN, int CR, int T) {
+    if (BN == 1 || CR <= 0 || T <= 0) return 0;
+    return cdiv(N, BN) + plan_max_chunks(N, E, R, BN, CR) / T + 1;      // every block one item, heavy ones chunks/T more
+}
+
 int64_t plan_max_chunks(int64_t N, int64_t E, int R, int BN, int CR) {
     if (BN == 1 || CR <= 0) return 0;
     const int64_t nseg = num_segments(N, R, BN);
@@ -136,14 +180,15 @@ size_t plan_workspace_bytes(int64_t N, int64_t E, int R, int BN, int CR) {
     if (BN > 1 && CR > 0) {
         const int64_t nseg = num_segments(N, R, BN);
         b += align_up((size_t)nseg * 4, 256) * 2 + align_up(scan_temp_bytes(nseg), 256);
+        b += align_up((size_t)(cdiv(N, BN) + 1) * 4, 256) * 4;          // item counts and their scans
     }
     return b;
 }
 
 int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, int64_t E, int R,
-                      int BN, int CR, void* ws, size_t ws_bytes, uint32_t* sorted_key, int32_t* sorted_src,
+                      int BN, int CR, int T, void* ws, size_t ws_bytes, uint32_t* sorted_key, int32_t* sorted_src,
                       int32_t* seg_off, int32_t* indeg, int32_t* chunk_tab, int32_t* blk_chunk_off,
-                      int32_t* status, hipStream_t stream) {
+                      int32_t* item_tab, int32_t* blk_item_off, int32_t* status, hipStream_t stream) {
     GHF_REQUIRE(N > 0 && E > 0 && R > 0 && BN > 0, "plan: N, E, R, block_nodes must be positive");
     GHF_REQUIRE(E < (1ll << 31), "plan: E=%lld needs < 2^31 edges", (long long)E);
     const int64_t NB = cdiv(N, BN);
@@ -153,6 +198,7 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
     if (BN > 1) {
         GHF_REQUIRE(N <= (1ll << SRC_BITS), "plan: block plans pack the run head above bit %d of the source id", SRC_BITS);
         GHF_REQUIRE(CR > 0 && CR < 128 && (CR % 16) == 0 && R < (1 << 23), "plan: chunk_rows must be a multiple of 16 below 128, R < 2^23");
+        GHF_REQUIRE(T > 0 && item_tab && blk_item_off, "plan: block plans need split_chunks > 0, item_tab and blk_item_off");
     }
     GHF_REQUIRE(ws_bytes >= plan_workspace_bytes(N, E, R, BN, CR), "plan: workspace too small");
     GHF_REQUIRE(((uintptr_t)ws & 255) == 0, "plan: workspace must be 256-byte aligned");
@@ -164,7 +210,7 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
     size_t sort_bytes = sort_temp_bytes(E);
 
     GHF_HIP_CHECK(hipMemsetAsync(indeg, 0, (size_t)N * 4, stream));
-    GHF_HIP_CHECK(hipMemsetAsync(status, 0, 4, stream));
+    GHF_HIP_CHECK(hipMemsetAsync(status, 0, 12, stream));
     const int tpb = 256;
     const int grid = (int)((E + tpb - 1) / tpb < 8192 ? (E + tpb - 1) / tpb : 8192);
     plan_keys_kernel<<<grid, tpb, 0, stream>>>(edge_index, rel_id, N, E, R, BN, keys_in, vals_in, indeg, status);
@@ -194,6 +240,19 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
         GHF_LAUNCH_CHECK();
         // heads for the valid edges only: seg_off[nseg] (device) bounds them, so the kernel re-reads it per edge
         plan_heads_kernel<<<(int)((E + 255) / 256), 256, 0, stream>>>(sorted_key, seg_off, E, (uint32_t)BN, sorted_src);
+        GHF_LAUNCH_CHECK();
+        // work items (status[1], status[2] = number of items, of scratch slots)
+        p = (char*)scan_tmp + align_up(scan_bytes, 256);
+        int32_t* ni = (int32_t*)p;               p += align_up((size_t)(NB + 1) * 4, 256);
+        int32_t* nslot = (int32_t*)p;            p += align_up((size_t)(NB + 1) * 4, 256);
+        int32_t* ioff = (int32_t*)p;             p += align_up((size_t)(NB + 1) * 4, 256);
+        int32_t* soff = (int32_t*)p;
+        const int gb = (int)((NB + 1 + 255) / 256);
+        plan_item_count_kernel<<<gb, 256, 0, stream>>>(blk_chunk_off, NB, T, ni, nslot);
+        GHF_LAUNCH_CHECK();
+        GHF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int32_t*)ni, ioff, (int)NB, stream));
+        GHF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int32_t*)nslot, soff, (int)NB, stream));
+        plan_item_fill_kernel<<<gb, 256, 0, stream>>>(blk_chunk_off, ni, ioff, soff, NB, item_tab, blk_item_off, status + 1);
         GHF_LAUNCH_CHECK();
     }
     return GHF_OK;

@@ -45,13 +45,29 @@ class GraphPlan:
     indeg: torch.Tensor            # [N] int32
     chunk_tab: Optional[torch.Tensor] = None       # [2*max_chunks] int32 (block plans)
     blk_chunk_off: Optional[torch.Tensor] = None   # [NB+1] int32 (block plans)
+    item_tab: Optional[torch.Tensor] = None        # [4*max_items] int32 work items (block plans)
+    blk_item_off: Optional[torch.Tensor] = None    # [NB+1] int32
+    item_off_host: Optional[np.ndarray] = None     # host copy of blk_item_off (launch geometry)
+    n_slots: int = 0                               # scratch slots (BN*d floats each) the split blocks need
+    _partial: Optional[torch.Tensor] = None
     chunk_rows: int = 0
     row_lo: int = 0                # destination rows this plan covers (multi-GPU shards)
     row_hi: int = 0
 
     def bytes(self) -> int:
-        ts = (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg, self.chunk_tab, self.blk_chunk_off)
+        ts = (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg, self.chunk_tab, self.blk_chunk_off,
+              self.item_tab, self.blk_item_off)
         return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+    def items_for(self, row0: int, rows: int, d: int):
+        """(first work item, item count, scratch) for the destination rows [row0, row0+rows) of a block plan."""
+        if self.block_nodes == 1:
+            return 0, 0, None
+        bn = self.block_nodes
+        i0, i1 = int(self.item_off_host[row0 // bn]), int(self.item_off_host[-(-(row0 + rows) // bn)])
+        if self.n_slots and (self._partial is None or self._partial.numel() < self.n_slots * bn * d):
+            self._partial = torch.empty(self.n_slots * bn * d, dtype=torch.float32, device=self.sorted_key.device)
+        return i0, i1 - i0, (self._partial if self.n_slots else None)
 
 
 def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: List[str], N: int, d: int,
@@ -68,7 +84,7 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     if E == 0:
         raise ValueError("edge_index has no edges; the reference cannot encode an empty relation list either")
     R = len(unique_texts)
-    bn, wl, cr = (1, _native.WLAYOUT_NATURAL, 0) if force_generic else _native.message_config(d)
+    bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else _native.message_config(d)
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range
@@ -84,19 +100,32 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
             nseg = N if bn == 1 else ((N + bn - 1) // bn) * R
             z = lambda n: torch.zeros(n, dtype=torch.int32, device=device)  # noqa: E731
             nb = (N + bn - 1) // bn
-            return GraphPlan(N=N, E=0, R=R, block_nodes=bn, wlayout=wl, unique_texts=unique_texts, rel_ids=rel,
-                             sorted_key=z(1), sorted_src=z(1), seg_off=z(nseg + 1), indeg=z(N),
-                             chunk_tab=z(2) if bn > 1 else None, blk_chunk_off=z(nb + 1) if bn > 1 else None,
-                             chunk_rows=cr, row_lo=lo, row_hi=hi)
-    skey, ssrc, seg_off, indeg, chunk_tab, blk_chunk_off, status = _native.plan_build(ei, rel, N, R, bn, cr)
-    st = int(status.item())                       # the only host sync of the plan
+            empty = GraphPlan(N=N, E=0, R=R, block_nodes=bn, wlayout=wl, unique_texts=unique_texts, rel_ids=rel,
+                              sorted_key=z(1), sorted_src=z(1), seg_off=z(nseg + 1), indeg=z(N), chunk_rows=cr,
+                              row_lo=lo, row_hi=hi)
+            if bn > 1:                                # one empty work item per block
+                items = np.zeros((nb, 4), dtype=np.int32)
+                items[:, 0], items[:, 3] = np.arange(nb), -1
+                empty.chunk_tab, empty.blk_chunk_off = z(2), z(nb + 1)
+                empty.item_tab = torch.from_numpy(items.reshape(-1)).to(device)
+                empty.item_off_host = np.arange(nb + 1, dtype=np.int32)
+                empty.blk_item_off = torch.from_numpy(empty.item_off_host).to(device)
+            return empty
+    pl = _native.plan_build(ei, rel, N, R, bn, cr, sc)
+    status = pl["status"].cpu().numpy()           # the only host sync of the plan
+    st = int(status[0])
     if st & 1:
         raise IndexError(f"edge_index holds node ids outside [0, {N})")
     if st & 2:
         raise IndexError(f"relation ids outside [0, {R})")
-    return GraphPlan(N=N, E=ei.size(1), R=R, block_nodes=bn, wlayout=wl, unique_texts=unique_texts, rel_ids=rel,
-                     sorted_key=skey, sorted_src=ssrc, seg_off=seg_off, indeg=indeg, chunk_tab=chunk_tab,
-                     blk_chunk_off=blk_chunk_off, chunk_rows=cr, row_lo=lo, row_hi=hi)
+    plan = GraphPlan(N=N, E=ei.size(1), R=R, block_nodes=bn, wlayout=wl, unique_texts=unique_texts, rel_ids=rel,
+                     sorted_key=pl["sorted_key"], sorted_src=pl["sorted_src"], seg_off=pl["seg_off"], indeg=pl["indeg"],
+                     chunk_tab=pl["chunk_tab"], blk_chunk_off=pl["blk_chunk_off"], item_tab=pl["item_tab"],
+                     blk_item_off=pl["blk_item_off"], chunk_rows=cr, row_lo=lo, row_hi=hi)
+    if bn > 1:
+        plan.item_off_host = pl["blk_item_off"].cpu().numpy()
+        plan.n_slots = int(status[2])
+    return plan
 
 
 def _texts_fingerprint(edge_texts: Sequence[str]) -> Tuple:

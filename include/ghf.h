@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 2
+#define GHF_ABI_VERSION 3
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -47,8 +47,8 @@ int         ghf_abi_version(void);
 const char* ghf_last_error(void);
 
 /* Which plan geometry and weight layout the message kernel for hidden size d wants.
- * block_nodes == 1 means "CSR by destination" (the generic kernel; chunk_rows == 0 then). */
-int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows);
+ * block_nodes == 1 means "CSR by destination" (the generic kernel; chunk_rows == split_chunks == 0 then). */
+int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks);
 
 /* ---- K0: graph plan -----------------------------------------------------------
  * Replaces the implicit edge order of models/hypergnn.py:191 (src,dst = edge_index)
@@ -66,16 +66,24 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows);
  *              chunk c = { first sorted edge, (rel << 8) | (cross << 7) | rows }, cross = a run of
  *              equal destinations spans a 16-row tile boundary inside the chunk; block b owns
  *              chunks [blk_chunk_off[b], blk_chunk_off[b+1]),
- *   status [1] int32: 0 ok, bit0 = a src/dst outside [0,N), bit1 = a rel outside [0,R)
- *   (read it back before trusting the plan; offending edges are dropped).
- * Requires ceil(N/BN)*BN*R < 2^32, E < 2^31, R < 2^23, chunk_rows % 16 == 0, chunk_rows < 128. */
+ *   item_tab [4*max_items] int32 and blk_item_off [ceil(N/BN)+1] int32 (BN > 1 only): the work items.
+ *              A block with more than split_chunks chunks (the hub of a power-law graph) is cut into
+ *              ceil(chunks/split_chunks) items; item i = { block, first chunk, one past its last chunk,
+ *              scratch slot (-1 for the only item of a block) }; block b owns items
+ *              [blk_item_off[b], blk_item_off[b+1]),
+ *   status [3] int32: [0] 0 ok, bit0 = a src/dst outside [0,N), bit1 = a rel outside [0,R) (read it back
+ *              before trusting the plan; offending edges are dropped); [1] number of items; [2] number of
+ *              scratch slots (each BN*d floats) ghf_message_layer_fwd needs in `partial`.
+ * Requires ceil(N/BN)*BN*R < 2^32, E < 2^31, R < 2^23, chunk_rows % 16 == 0, chunk_rows < 128, split_chunks > 0. */
 size_t  ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
 int64_t ghf_plan_max_chunks(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
+int64_t ghf_plan_max_items(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows, int split_chunks);
 int ghf_plan_build(const int64_t* edge_index /* [2,E] row 0 = src, row 1 = dst */,
                    const int64_t* rel_id /* [E] */, int64_t N, int64_t E, int R, int block_nodes,
-                   int chunk_rows, void* workspace, size_t workspace_bytes,
+                   int chunk_rows, int split_chunks, void* workspace, size_t workspace_bytes,
                    uint32_t* sorted_key, int32_t* sorted_src, int32_t* seg_off, int32_t* indeg,
-                   int32_t* chunk_tab, int32_t* blk_chunk_off, int32_t* status, void* stream);
+                   int32_t* chunk_tab, int32_t* blk_chunk_off, int32_t* item_tab, int32_t* blk_item_off,
+                   int32_t* status, void* stream);
 
 /* ---- K1: weight generation ------------------------------------------------------
  * Replaces models/weight_generator.py:137-141 (three nn.Sequential heads, reshape,
@@ -104,11 +112,16 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
  *   h'_v  = LayerNorm(ReLU(out_v + h_v))              
  * for destination rows [row0, row0+rows) (row0 % block_nodes == 0); other rows of
  * h_out are not touched.  The plan arrays must come from ghf_plan_build with the
- * same N, E, R, block_nodes; W/bias from ghf_weightgen_fwd with `wlayout`. */
+ * same N, E, R, block_nodes; W/bias from ghf_weightgen_fwd with `wlayout`.
+ * item0 / n_items: the work items of the blocks of the row range, i.e. blk_item_off[row0/BN] and
+ * blk_item_off[ceil((row0+rows)/BN)] - item0 (host copies of two plan words); partial: scratch of
+ * status[2]*BN*d floats for the split blocks (may be NULL when status[2] == 0). */
 int ghf_message_layer_fwd(const float* h /* [N,d] */, int64_t N, int d,
                           const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg,
                           const int32_t* chunk_tab, const int32_t* blk_chunk_off,
+                          const int32_t* item_tab, const int32_t* blk_item_off,
+                          int64_t item0, int64_t n_items, float* partial,
                           int64_t E, int R, int block_nodes,
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps,

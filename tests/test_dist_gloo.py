@@ -29,7 +29,7 @@ class OracleOps:
         self.bn = block_nodes
 
     def message_config(self, d):
-        return self.bn, 0, 48
+        return self.bn, 0, 48, 128
 
     def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner):
         S, G, g = owner

@@ -38,8 +38,8 @@ def test_native_library_is_loaded():
     lib = _native.load()
     assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
-    assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48)
-    assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0)
+    assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48, 128)
+    assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
 
 
 # ---- golden vectors from the reference -----------------------------------------------------
@@ -117,13 +117,14 @@ def test_frag16_layout_is_a_permutation_of_natural():
 
 # ---- K0 plan properties -----------------------------------------------------------------------
 
-@pytest.mark.parametrize("bn,cr", [(1, 0), (216, 48), (432, 96)])
-def test_plan_is_a_sorted_permutation_of_the_edges(bn, cr):
+@pytest.mark.parametrize("bn,cr,sc", [(1, 0, 0), (216, 48, 128), (432, 96, 4)])
+def test_plan_is_a_sorted_permutation_of_the_edges(bn, cr, sc):
     N, E, R = 5000, 60000, 13
     ei, rel = synth.make_graph_arrays(N, E, R, seed=77, kind="powerlaw")
-    sk, ss, off, indeg, ctab, boff, status = _native.plan_build(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV),
-                                                                N, R, bn, cr)
-    assert int(status.item()) == 0
+    pl = _native.plan_build(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), N, R, bn, cr, sc)
+    sk, ss, off, indeg, ctab, boff, status = (pl[k] for k in ("sorted_key", "sorted_src", "seg_off", "indeg", "chunk_tab",
+                                                              "blk_chunk_off", "status"))
+    assert int(status[0].item()) == 0
     key = sk.cpu().numpy().view(np.uint32).astype(np.int64)
     assert (np.diff(key) >= 0).all()
     blk, rem = key // (R * bn), key % (R * bn)
@@ -169,6 +170,25 @@ def test_plan_is_a_sorted_permutation_of_the_edges(bn, cr):
         want_cross = any(key[e0[c] + b - 1] == key[e0[c] + b] for b in range(16, rows[c], 16))
         assert cross[c] == int(want_cross)
         assert (e0[c] - off[seg[e0[c]]]) % cr == 0
+    # work items: a block's chunks in order, cut evenly into ceil(chunks / sc) items when there are more than sc
+    ioff = pl["blk_item_off"].cpu().numpy()
+    n_items, n_slots = int(status[1].item()), int(status[2].item())
+    items = pl["item_tab"].cpu().numpy()[: 4 * n_items].reshape(-1, 4)
+    assert ioff.shape == (nb + 1,) and ioff[0] == 0 and ioff[-1] == n_items
+    slots = []
+    for b in range(nb):
+        mine = items[ioff[b]:ioff[b + 1]]
+        nchunks = boff[b + 1] - boff[b]
+        assert len(mine) == (-(-nchunks // sc) if nchunks > sc else 1)
+        assert (mine[:, 0] == b).all() and mine[0, 1] == boff[b] and mine[-1, 2] == boff[b + 1]
+        assert (mine[1:, 1] == mine[:-1, 2]).all() and (mine[:, 2] >= mine[:, 1]).all()
+        if len(mine) > 1:
+            assert (mine[:, 2] - mine[:, 1]).max() <= sc
+            slots += mine[:, 3].tolist()
+        else:
+            assert mine[0, 3] == -1
+    assert slots == list(range(n_slots))
+    assert n_slots > 0 or sc != 4                                       # a small threshold splits this graph for sure
 
 
 def test_plan_flags_out_of_range_ids():
@@ -225,6 +245,38 @@ def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail):
         out2 = torch.empty_like(h_d)
         _native.tail_fwd(out, h_d, t(gamma), t(beta), 1e-5, out2)
         assert_close(out2.cpu().numpy(), O.layer_tail(ref, th(h), th(gamma), th(beta)).numpy(), "tail_fwd")
+
+
+@pytest.mark.parametrize("d", [128, 64])
+def test_split_hub_blocks_match_oracle(d):
+    """Power-law in-degrees: blocks with more chunks than split_chunks are cut into work items whose partial sums a
+    second kernel combines in item order (ghf.h: item_tab) — same result, still bitwise reproducible."""
+    N, E, R = 6000, 150000, 8
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=4242, kind="powerlaw")
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    nb = -(-N // plan.block_nodes)
+    n_items = int(plan.item_off_host[-1])
+    assert plan.n_slots > 0 and n_items > nb, "this graph must have split blocks"
+    assert np.any(np.diff(plan.item_off_host) == 1), "and unsplit ones"
+    W, h_d = t(_to_frag16(Wm, Ws)), t(h)
+    th = torch.from_numpy
+    agg = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
+    for no_tail in (False, True):
+        out = torch.full_like(h_d, float("nan"))
+        g, bt = (None, None) if no_tail else (t(gamma), t(beta))
+        flags = _native.GHF_FLAG_NO_TAIL if no_tail else 0
+        _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, g, bt, 1e-5, out, flags=flags)
+        ref = agg if no_tail else O.layer_tail(agg, th(h), th(gamma), th(beta))
+        assert_close(out.cpu().numpy(), ref.numpy(), f"split blocks d={d} no_tail={no_tail}")
+        again = torch.empty_like(h_d)
+        _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, g, bt, 1e-5, again, flags=flags)
+        assert torch.equal(out, again)
+        bn = plan.block_nodes
+        part = torch.full_like(h_d, 7.0)
+        _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, g, bt, 1e-5, part, row0=bn, rows=3 * bn, flags=flags)
+        assert torch.equal(part[bn:4 * bn], out[bn:4 * bn])
+        assert (part[:bn] == 7.0).all() and (part[4 * bn:] == 7.0).all()
 
 
 def test_row_range_only_touches_its_rows():

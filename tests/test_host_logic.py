@@ -23,22 +23,24 @@ def test_library_exports_every_symbol_of_the_header():
     assert set(names) == set(_native.SIGNATURES), "include/ghf.h and _native.SIGNATURES disagree"
     for n in names:
         assert hasattr(lib, n), f"libghf_hip.so does not export {n}"
-    assert lib.ghf_abi_version() == _native.ABI_VERSION == 2
+    assert lib.ghf_abi_version() == _native.ABI_VERSION == 3
 
 
 def test_abi_argument_validation_without_a_gpu():
     """Pure host-side checks of the C ABI (no kernel is launched)."""
     lib = _native.load()
-    bn, wl, cr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    bn, wl, cr, sc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     ref = ctypes.byref
-    assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr)) == 0
-    assert (bn.value, wl.value, cr.value) == (216, 1, 48)
-    assert lib.ghf_message_config(64, ref(bn), ref(wl), ref(cr)) == 0 and (bn.value, cr.value) == (216, 48)
-    assert lib.ghf_message_config(20, ref(bn), ref(wl), ref(cr)) == 0 and (bn.value, wl.value, cr.value) == (1, 0, 0)
-    assert lib.ghf_message_config(16, None, None, None) == -1
+    assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
+    assert (bn.value, wl.value, cr.value, sc.value) == (216, 1, 48, 128)
+    assert lib.ghf_message_config(64, ref(bn), ref(wl), ref(cr), ref(sc)) == 0 and (bn.value, cr.value) == (216, 48)
+    assert lib.ghf_message_config(20, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
+    assert (bn.value, wl.value, cr.value, sc.value) == (1, 0, 0, 0)
+    assert lib.ghf_message_config(16, None, None, None, None) == -1
     assert b"null" in lib.ghf_last_error()
     assert lib.ghf_plan_max_chunks(1000, 5000, 7, 216, 48) >= 5000 // 48 + 1
     assert lib.ghf_plan_max_chunks(1000, 5000, 7, 1, 0) == 0
+    assert lib.ghf_plan_max_items(1000, 5000, 7, 216, 48, 128) >= 5
     assert lib.ghf_input_proj_fwd(None, None, None, 4, 4, 4, None, None) == -1
     assert lib.ghf_tail_fwd(None, None, None, None, 1e-5, 0, 1, 8, None, None) == -1
 
