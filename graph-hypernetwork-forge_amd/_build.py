@@ -10,17 +10,21 @@ from typing import List
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-# GHF_VARIANT=stamps selects the diagnostic build (-DGHF_STAMPS, in-kernel s_memtime stamps); never the product
+# GHF_VARIANT=stamps selects the diagnostic build (-DGHF_STAMPS, in-kernel s_memtime stamps), GHF_VARIANT=ablate the
+# one whose message kernels honour GHF_DEBUG_FLAGS (-DGHF_ABLATE: pieces of work switched off, wrong results);
+# neither is ever the product
 VARIANT = os.environ.get("GHF_VARIANT", "")
 OBJ_DIR = os.path.join(CSRC, "_obj" + ("_" + VARIANT if VARIANT else ""))
 LIB_PATH = os.path.join(PKG_DIR, "libghf_hip" + ("_" + VARIANT if VARIANT else "") + ".so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["capi.hip", "plan.hip", "weightgen.hip", "input_proj.hip", "message_generic.hip", "message_mfma.hip", "message_pp.hip"]
+SOURCES = ["capi.hip", "plan.hip", "weightgen.hip", "input_proj.hip", "message_generic.hip", "message_mfma.hip", "message_pp.hip", "message_sx.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ghf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 if VARIANT == "stamps":
     FLAGS.append("-DGHF_STAMPS")
+elif VARIANT == "ablate":
+    FLAGS.append("-DGHF_ABLATE")
 
 
 def hipcc_path() -> str:

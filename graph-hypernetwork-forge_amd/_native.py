@@ -25,6 +25,7 @@ GHF_FLAG_NO_TAIL = 1
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
 WLAYOUT_FRAG16 = 1
+WLAYOUT_SPLIT3 = 2          # bf16 B fragments, 3 exact pieces per weight (6 bytes each) in an opaque float32 buffer
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -167,8 +168,9 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
     ls = _req(log_scales, torch.float32, "log_scales")
     hidden_ws = torch.empty(3 * 2 * R * max(Hh, T, 1), dtype=torch.float32, device=dev)
     if out is None:
-        if layout == WLAYOUT_FRAG16:
-            W_msg = torch.empty(2 * R * d_in * d_out, dtype=torch.float32, device=dev)
+        if layout in (WLAYOUT_FRAG16, WLAYOUT_SPLIT3):
+            words = (2 if layout == WLAYOUT_FRAG16 else 3) * R * d_in * d_out
+            W_msg = torch.empty(words, dtype=torch.float32, device=dev)
             W_self = None
         else:
             W_msg = torch.empty(R, d_in, d_out, dtype=torch.float32, device=dev)

@@ -1,6 +1,7 @@
 // capi.hip — the extern "C" surface declared in include/ghf.h.
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace ghf {
@@ -31,7 +32,15 @@ const char* ghf_last_error(void) { return err_buf(); }
 int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks) {
     if (!block_nodes || !wlayout || !chunk_rows || !split_chunks) return set_err(GHF_EINVAL, "message_config: null output pointer");
     int bn = 1, cr = 0, sc = 0;
-    if (message_mfma_config(d, &bn, &cr, &sc)) {
+    // GHF_KERNEL selects the contraction for A/B runs: "sx" (default) = split-bf16 on the bf16 matrix pipe where a
+    // kernel exists, "pp" / "lockstep" = v_mfma_f32_16x16x4_f32 (message_pp.hip / message_mfma.hip)
+    const char* kv = getenv("GHF_KERNEL");
+    if ((!kv || !strcmp(kv, "sx")) && message_sx_config(d, &bn, &cr, &sc)) {
+        *block_nodes = bn;
+        *wlayout = GHF_WLAYOUT_SPLIT3;
+        *chunk_rows = cr;
+        *split_chunks = sc;
+    } else if (message_mfma_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_FRAG16;
         *chunk_rows = cr;
@@ -106,6 +115,7 @@ int ghf_message_layer_fwd(const float* h, int64_t N, int d, const uint32_t* sort
               partial, E, R, block_nodes, W_msg, W_self, bias, wlayout,
               ln_gamma, ln_beta, ln_eps, row0, rows, h_out, flags};
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
+    if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
     return launch_message_mfma(a, (hipStream_t)stream);
 }
 

@@ -102,6 +102,8 @@ int launch_message_generic(const MsgArgs& a, hipStream_t stream);
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
 int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)
 bool message_mfma_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
+int launch_message_sx(const MsgArgs& a, hipStream_t stream);       // split-bf16 contraction (d = 128), SPLIT3 weights
+bool message_sx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 int launch_combine_split(const MsgArgs& a, hipStream_t stream);     // sums the partial slots of split blocks + tail
 
 int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,

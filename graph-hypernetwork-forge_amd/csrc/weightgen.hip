@@ -60,6 +60,21 @@ __device__ __forceinline__ size_t frag16_index(int r, int kk, int o, int d) {
     return ((((size_t)r * NT + (o >> 4)) * NJ2 + (kk >> 4)) * 64 + (((kk & 15) >> 2) << 4) + (o & 15)) * 4 + (kk & 3);
 }
 
+// GHF_WLAYOUT_SPLIT3: x = p0 + p1 + p2 exactly, p_i = the i-th group of 8 significand bits as a bf16 (truncation);
+// element (r, kk, o) of the combined matrix lives, piece by piece, at
+//   Wsplit[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8]   (bf16 units), kk in [0, 2d).
+__device__ __forceinline__ size_t split3_index(int r, int kk, int o, int d) {           // of piece 0; pieces are 512 apart
+    const int NT = d >> 4, NKS = d >> 4;
+    return ((((size_t)r * NT + (o >> 4)) * NKS + (kk >> 5)) * 3 * 64 + (((kk & 31) >> 3) << 4) + (o & 15)) * 8 + (kk & 7);
+}
+__device__ __forceinline__ void split3_pieces(float x, uint16_t (&p)[3]) {
+    const uint32_t u1 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(u1 & 0xFFFF0000u);
+    const uint32_t u2 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u2 & 0xFFFF0000u);
+    p[0] = (uint16_t)(u1 >> 16); p[1] = (uint16_t)(u2 >> 16); p[2] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 // Vector-ALU last layer: one wave per output element n (lanes stride K), looping relations.
 // grid (ceil(n_out / 4)), block 256 (4 waves).
 __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restrict__ z /* [R,Hl] */,
@@ -80,6 +95,12 @@ __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restr
             const float v = (s + bn) * scale;
             if (head == 2 || layout == GHF_WLAYOUT_NATURAL) {
                 out[(size_t)r * n_out + n] = v;
+            } else if (layout == GHF_WLAYOUT_SPLIT3) {
+                const int i = n / d_out, o = n - i * d_out;
+                uint16_t pc[3];
+                split3_pieces(v, pc);
+                uint16_t* dst = (uint16_t*)out + split3_index(r, head * d_in + i, o, d_out);
+                for (int pl = 0; pl < 3; ++pl) dst[pl * 512] = pc[pl];
             } else {
                 const int i = n / d_out, o = n - i * d_out;
                 out[frag16_index(r, head * d_in + i, o, d_out)] = v;
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restric
     // row n handled by this lane as A-operand supplier (row = lane & 15)
     int n_a;
     int o = 0, it = 0;
-    if (LAYOUT == GHF_WLAYOUT_FRAG16) {
+    if (LAYOUT != GHF_WLAYOUT_NATURAL) {
         const int tiles_per_o = d >> 4;                  // i-tiles per output column
         o = mt / tiles_per_o;
         it = mt - o * tiles_per_o;
@@ -142,7 +163,23 @@ __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restric
         }
         // D layout: lane holds rows 4q + reg (reg 0..3), column c16 (= relation rc)
         if (!b_ok) continue;
-        if (LAYOUT == GHF_WLAYOUT_FRAG16) {
+        if (LAYOUT == GHF_WLAYOUT_SPLIT3) {
+            // rows 4q..4q+3 = four consecutive kk of one lane slot: 8 bytes per piece
+            uint16_t pc[4][3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = (16 * it + 4 * q + s) * d + o;
+                split3_pieces((acc[s] + b3[n]) * scale, pc[s]);
+            }
+            const int kk0 = head * d + 16 * it + 4 * q;   // kk & 3 == 0
+            uint16_t* dst = (uint16_t*)out + split3_index(rc, kk0, o, d);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const uint2 v = make_uint2((uint32_t)pc[0][pl] | ((uint32_t)pc[1][pl] << 16),
+                                           (uint32_t)pc[2][pl] | ((uint32_t)pc[3][pl] << 16));
+                *(uint2*)(dst + pl * 512) = v;
+            }
+        } else if (LAYOUT == GHF_WLAYOUT_FRAG16) {
             f32x4 v;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -168,10 +205,14 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
     GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
     GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
     GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
-    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16, "weightgen: bad layout %d", layout);
+    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT3,
+                "weightgen: bad layout %d", layout);
     if (layout == GHF_WLAYOUT_FRAG16)
         GHF_REQUIRE(d_in == d_out && (d_in % 16) == 0 && W_self == nullptr,
                     "weightgen: FRAG16 needs d_in == d_out, d %% 16 == 0 and W_self == NULL");
+    else if (layout == GHF_WLAYOUT_SPLIT3)
+        GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && W_self == nullptr,
+                    "weightgen: SPLIT3 needs d_in == d_out, d %% 32 == 0 and W_self == NULL");
     else
         GHF_REQUIRE(W_self != nullptr, "weightgen: NATURAL layout needs W_self");
 
@@ -193,10 +234,14 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
         const float* W3 = P.w[head][num_hidden];
         const float* b3 = P.b[head][num_hidden];
         const int n_out = head == 2 ? d_out : n_mat;
-        float* out = head == 2 ? bias : (layout == GHF_WLAYOUT_FRAG16 ? W_msg : (head == 0 ? W_msg : W_self));
+        float* out = head == 2 ? bias : (layout != GHF_WLAYOUT_NATURAL ? W_msg : (head == 0 ? W_msg : W_self));
         const bool mfma_ok = head != 2 && (Hl % 16) == 0 &&
                              ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
-        if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
+        if (mfma_ok && layout == GHF_WLAYOUT_SPLIT3) {
+            const int mtiles = n_mat / 16;
+            wg_out_mfma_kernel<GHF_WLAYOUT_SPLIT3><<<(mtiles + 3) / 4, 256, 0, stream>>>(
+                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);
+        } else if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
                 z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);

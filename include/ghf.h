@@ -42,6 +42,8 @@ extern "C" {
 /* Weight layouts produced by ghf_weightgen_fwd and consumed by ghf_message_layer_fwd */
 #define GHF_WLAYOUT_NATURAL 0 /* W_msg[R][d_in][d_out], W_self[R][d_in][d_out] row-major, as the reference returns them */
 #define GHF_WLAYOUT_FRAG16  1 /* MFMA 16x16x4 B-fragment order: Wfrag[R][d/16][2d/16][64 lanes][4] */
+#define GHF_WLAYOUT_SPLIT3  2 /* bf16 MFMA 16x16x32 B-fragment order, every fp32 weight cut exactly into 3 bf16 pieces:
+                                 Wsplit[R][d/16][2d/32][3 pieces][64 lanes][8] bf16 = 6 bytes per weight */
 
 int         ghf_abi_version(void);
 const char* ghf_last_error(void);

@@ -38,8 +38,14 @@ def test_native_library_is_loaded():
     lib = _native.load()
     assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
-    assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48, 128)
+    assert _native.message_config(128) == (162, _native.WLAYOUT_SPLIT3, 48, 128)
+    assert _native.message_config(64) == (216, _native.WLAYOUT_FRAG16, 48, 128)
     assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
+    os.environ["GHF_KERNEL"] = "pp"
+    try:
+        assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48, 128)
+    finally:
+        del os.environ["GHF_KERNEL"]
 
 
 # ---- golden vectors from the reference -----------------------------------------------------
@@ -113,6 +119,61 @@ def test_frag16_layout_is_a_permutation_of_natural():
     f = Wf.view(R, d // 16, 2 * d // 16, 4, 16, 4)                     # r, nt, j, q, c16, s
     back = f.permute(0, 2, 3, 5, 1, 4).reshape(R, 2 * d, d)            # kk = 16j + 4q + s ; o = 16nt + c16
     assert torch.equal(back, cat)
+
+
+def _split3_np(x):
+    """x = p0 + p1 + p2 exactly; p_i = the i-th group of 8 significand bits as bf16 bit patterns (uint16)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u1 = x.view(np.uint32)
+    r1 = x - (u1 & np.uint32(0xFFFF0000)).view(np.float32)
+    u2 = r1.view(np.uint32)
+    r2 = r1 - (u2 & np.uint32(0xFFFF0000)).view(np.float32)
+    return [(u >> 16).astype(np.uint16) for u in (u1, u2, r2.view(np.uint32))]
+
+
+def _bf16_np(p):
+    return (p.astype(np.uint32) << 16).view(np.float32)
+
+
+def _to_split3(Wm, Ws):
+    """Wsplit[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8] bf16, as an opaque float32 buffer."""
+    R, d, _ = Wm.shape
+    cat = np.concatenate([Wm, Ws], axis=1)                                                # [R, 2d, d]
+    pc = np.stack(_split3_np(cat)).reshape(3, R, 2 * d // 32, 4, 8, d // 16, 16)          # piece, r, ks, q, e, ct, c16
+    return np.ascontiguousarray(pc.transpose(1, 5, 2, 0, 3, 6, 4)).reshape(-1).view(np.float32)   # r, ct, ks, piece, q, c16, e
+
+
+def test_split3_layout_is_an_exact_three_piece_cut_of_natural():
+    c = [x for x in cases.WG_CASES if x.name == "wg_c3_shape"][0]
+    gen = WeightGenerator(c.text_dim, c.d_in, c.d_out, hidden_dim=c.hidden_dim)
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in c.params().items()})
+    gen = gen.to(DEV).eval()
+    x = torch.from_numpy(c.text_emb()).to(DEV)
+    with torch.no_grad():
+        Wm, Ws, b = gen.generate(x, _native.WLAYOUT_NATURAL)
+        Wsp, none, b2 = gen.generate(x, _native.WLAYOUT_SPLIT3)
+    assert none is None and torch.equal(b, b2)
+    Wm, Ws = Wm.cpu().numpy(), Ws.cpu().numpy()
+    assert np.array_equal(Wsp.cpu().numpy().view(np.uint16), _to_split3(Wm, Ws).view(np.uint16))
+    p = _split3_np(np.concatenate([Wm, Ws], axis=1))
+    assert np.array_equal((_bf16_np(p[0]) + _bf16_np(p[1])) + _bf16_np(p[2]), np.concatenate([Wm, Ws], axis=1))
+
+
+def _pack_weights(plan, Wm, Ws):
+    """(W, W_self) device tensors in the layout the plan's kernel reads."""
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    if plan.wlayout == _native.WLAYOUT_SPLIT3:
+        return t(_to_split3(Wm, Ws)), None
+    if plan.wlayout == _native.WLAYOUT_FRAG16:
+        return t(_to_frag16(Wm, Ws)), None
+    return t(Wm), t(Ws)
+
+
+@pytest.fixture(params=["sx", "pp"])
+def kernel(request, monkeypatch):
+    """Both contractions of the d = 128 message kernel: split-bf16 (default) and v_mfma_f32_16x16x4_f32."""
+    monkeypatch.setenv("GHF_KERNEL", request.param)
+    return request.param
 
 
 # ---- K0 plan properties -----------------------------------------------------------------------
@@ -224,14 +285,13 @@ def _to_frag16(Wm, Ws):
     (20, 400, 3000, 7, "uniform"), (16, 300, 2000, 4, "powerlaw"), (256, 300, 2400, 9, "uniform"),
 ])
 @pytest.mark.parametrize("no_tail", [False, True])
-def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail):
+def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail, kernel):
+    if kernel == "pp" and d != 128:
+        pytest.skip("only d = 128 has two contractions")
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=1000 + d + R, kind=kind)
     plan = build_plan(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), [""] * R, N, d, DEV)
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
-    if plan.wlayout == _native.WLAYOUT_FRAG16:
-        W, W2 = t(_to_frag16(Wm, Ws)), None
-    else:
-        W, W2 = t(Wm), t(Ws)
+    W, W2 = _pack_weights(plan, Wm, Ws)
     h_d = t(h)
     out = torch.full_like(h_d, float("nan"))
     _native.message_layer_fwd(h_d, plan, W, W2, t(b), plan.wlayout, None if no_tail else t(gamma),
@@ -248,9 +308,11 @@ def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail):
 
 
 @pytest.mark.parametrize("d", [128, 64])
-def test_split_hub_blocks_match_oracle(d):
+def test_split_hub_blocks_match_oracle(d, kernel):
     """Power-law in-degrees: blocks with more chunks than split_chunks are cut into work items whose partial sums a
     second kernel combines in item order (ghf.h: item_tab) — same result, still bitwise reproducible."""
+    if kernel == "pp" and d != 128:
+        pytest.skip("only d = 128 has two contractions")
     N, E, R = 6000, 150000, 8
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=4242, kind="powerlaw")
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
@@ -259,7 +321,7 @@ def test_split_hub_blocks_match_oracle(d):
     n_items = int(plan.item_off_host[-1])
     assert plan.n_slots > 0 and n_items > nb, "this graph must have split blocks"
     assert np.any(np.diff(plan.item_off_host) == 1), "and unsplit ones"
-    W, h_d = t(_to_frag16(Wm, Ws)), t(h)
+    W, h_d = _pack_weights(plan, Wm, Ws)[0], t(h)
     th = torch.from_numpy
     agg = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
     for no_tail in (False, True):
@@ -279,12 +341,12 @@ def test_split_hub_blocks_match_oracle(d):
         assert (part[:bn] == 7.0).all() and (part[4 * bn:] == 7.0).all()
 
 
-def test_row_range_only_touches_its_rows():
+def test_row_range_only_touches_its_rows(kernel):
     d, N, E, R = 128, 2000, 20000, 16
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=5, kind="uniform")
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
-    W = t(_to_frag16(Wm, Ws))
+    W = _pack_weights(plan, Wm, Ws)[0]
     full = torch.empty(N, d, device=DEV)
     _native.message_layer_fwd(t(h), plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, full)
     part = torch.full((N, d), 7.0, device=DEV)
@@ -343,7 +405,7 @@ def test_relation_order_does_not_matter():
 
 # ---- BASELINE config 3 at full size: size-independent properties + sampled rows vs the oracle --
 
-def test_full_size_c3_layer_properties():
+def test_full_size_c3_layer_properties(kernel):
     N, E, R, d = 1_000_000, 10_000_000, 64, 128
     ei, rel = synth.make_graph_arrays(N, E, R, seed=1003)
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -354,7 +416,7 @@ def test_full_size_c3_layer_properties():
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
     assert plan.E == E and int(plan.indeg.sum().item()) == E
-    W = t(_to_frag16(Wm, Ws))
+    W = _pack_weights(plan, Wm, Ws)[0]
     h_d = h.to(DEV)
     out1, out2 = torch.empty_like(h_d), torch.empty_like(h_d)
     args = (h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5)

@@ -32,7 +32,13 @@ def test_abi_argument_validation_without_a_gpu():
     bn, wl, cr, sc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     ref = ctypes.byref
     assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
-    assert (bn.value, wl.value, cr.value, sc.value) == (216, 1, 48, 128)
+    assert (bn.value, wl.value, cr.value, sc.value) == (162, 2, 48, 128)      # split-bf16 contraction (default)
+    os.environ["GHF_KERNEL"] = "pp"
+    try:
+        assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
+        assert (bn.value, wl.value, cr.value, sc.value) == (216, 1, 48, 128)  # fp32 MFMA contraction
+    finally:
+        del os.environ["GHF_KERNEL"]
     assert lib.ghf_message_config(64, ref(bn), ref(wl), ref(cr), ref(sc)) == 0 and (bn.value, cr.value) == (216, 48)
     assert lib.ghf_message_config(20, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
     assert (bn.value, wl.value, cr.value, sc.value) == (1, 0, 0, 0)

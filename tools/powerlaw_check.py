@@ -14,7 +14,9 @@ for kind in ("uniform", "powerlaw"):
     plan = build_plan(torch.from_numpy(ei).to(dev), torch.from_numpy(rel).to(dev), [""] * R, N, d, dev)
     boff = plan.blk_chunk_off.cpu().numpy()
     per_blk = np.diff(boff)
-    h = torch.randn(N, d, device=dev); W = torch.randn(2 * R * d * d, device=dev) * 0.05
+    h = torch.randn(N, d, device=dev); W = torch.randn((3 if plan.wlayout == _native.WLAYOUT_SPLIT3 else 2) * R * d * d, device=dev) * 0.05
+    if plan.wlayout == _native.WLAYOUT_SPLIT3:
+        W = (W.view(torch.int32) & 0x3FFF3FFF).view(torch.float32)
     b = torch.randn(R, d, device=dev); g = torch.ones(d, device=dev); bt = torch.zeros(d, device=dev)
     out = torch.empty_like(h)
     for _ in range(2):

@@ -25,7 +25,9 @@ dev = torch.device("cuda:0")
 ei, rel = synth.make_graph_arrays(N, E, R, 1003)
 plan = build_plan(torch.from_numpy(ei).to(dev), torch.from_numpy(rel).to(dev), [""] * R, N, d, dev)
 h = torch.randn(N, d, device=dev)
-W = torch.randn(2 * R * d * d, device=dev) * 0.05
+W = torch.randn((3 if plan.wlayout == _native.WLAYOUT_SPLIT3 else 2) * R * d * d, device=dev) * 0.05
+if plan.wlayout == _native.WLAYOUT_SPLIT3:          # any finite bf16 bit patterns will do for timing
+    W = (W.view(torch.int32) & 0x3FFF3FFF).view(torch.float32)
 b = torch.randn(R, d, device=dev)
 g, bt = torch.ones(d, device=dev), torch.zeros(d, device=dev)
 out = torch.empty_like(h)
@@ -35,7 +37,8 @@ torch.cuda.synchronize()
 nb = min(8192, -(-N // plan.block_nodes))
 buf = np.zeros(8192 * 8 * 8, dtype=np.uint64)
 lockstep = os.environ.get("GHF_KERNEL") == "lockstep" or d != 128
-fn = lib.ghf_debug_read_stamps if lockstep else lib.ghf_debug_read_stamps_pp
+fn = lib.ghf_debug_read_stamps if lockstep else (lib.ghf_debug_read_stamps_sx if plan.wlayout == _native.WLAYOUT_SPLIT3
+                                                 else lib.ghf_debug_read_stamps_pp)
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.size) == 0
