@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 GHF_FLAG_NO_TAIL = 1
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
@@ -42,9 +42,10 @@ SIGNATURES = {
     "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                  _vp, _vp, _vp, _vp]),
     "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "ghf_message_layer_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
+    "ghf_message_layer_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
                                      _vp, _vp, _vp, _i32,
-                                     _vp, _vp, _f32, _i64, _i64, _vp, _i32, _vp]),
+                                     _vp, _vp, _f32, _i64, _i64, _vp, _vp, _i32, _vp]),
+    "ghf_split3_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _vp]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
 }
 
@@ -198,22 +199,39 @@ def input_proj_fwd(x: torch.Tensor, W_in: torch.Tensor, b_in: torch.Tensor, out:
     return h0
 
 
+def split3_rows(h: torch.Tensor, out: Optional[torch.Tensor] = None, row0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
+    """Rows of h cut exactly into three bf16 pieces: [N, 3, d] (bf16 bit patterns in an int16 tensor)."""
+    h = _req(h, torch.float32, "h")
+    N, d = h.shape
+    if out is None:
+        out = torch.empty(N, 3, d, dtype=torch.int16, device=h.device)
+    rows = N - row0 if rows is None else rows
+    _check(load().ghf_split3_rows(_ptr(h), N, d, row0, rows, _ptr(out), _stream()), "ghf_split3_rows")
+    return out
+
+
 def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Optional[torch.Tensor],
                       bias: torch.Tensor, wlayout: int, ln_gamma: Optional[torch.Tensor],
                       ln_beta: Optional[torch.Tensor], ln_eps: float, h_out: torch.Tensor,
-                      row0: int = 0, rows: Optional[int] = None, flags: int = 0) -> torch.Tensor:
-    """`plan` is a plan.GraphPlan: the device arrays, the host copy of the item offsets and the split-block scratch."""
+                      row0: int = 0, rows: Optional[int] = None, flags: int = 0,
+                      h_split: Optional[torch.Tensor] = None, h_split_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`plan` is a plan.GraphPlan: the device arrays, the host copy of the item offsets and the split-block scratch.
+    SPLIT3 plans gather from `h_split` (split3_rows(h); made here when the caller has none) and can emit the split
+    form of the rows they write into `h_split_out` for the next layer."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
     if rows is None:
         rows = N - row0
     item0, n_items, partial = plan.items_for(row0, rows, d)
-    _check(lib.ghf_message_layer_fwd(_ptr(h), N, d, _ptr(plan.sorted_key), _ptr(plan.sorted_src), _ptr(plan.seg_off),
+    if wlayout == WLAYOUT_SPLIT3 and h_split is None:
+        h_split = split3_rows(h)
+    _check(lib.ghf_message_layer_fwd(_ptr(h), _ptr(h_split), N, d, _ptr(plan.sorted_key), _ptr(plan.sorted_src), _ptr(plan.seg_off),
                                      _ptr(plan.indeg), _ptr(plan.chunk_tab), _ptr(plan.blk_chunk_off), _ptr(plan.item_tab),
                                      _ptr(plan.blk_item_off), item0, n_items, _ptr(partial), plan.E, plan.R,
                                      plan.block_nodes, _ptr(W_msg), _ptr(W_self), _ptr(bias), wlayout, _ptr(ln_gamma),
-                                     _ptr(ln_beta), float(ln_eps), row0, rows, _ptr(h_out), flags, _stream()),
+                                     _ptr(ln_beta), float(ln_eps), row0, rows, _ptr(h_out), _ptr(h_split_out), flags,
+                                     _stream()),
            "ghf_message_layer_fwd")
     return h_out
 

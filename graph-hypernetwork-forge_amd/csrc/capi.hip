@@ -94,13 +94,19 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in, int
     return launch_input_proj(x, W_in, b_in, N, F, d, h0, (hipStream_t)stream);
 }
 
-int ghf_message_layer_fwd(const float* h, int64_t N, int d, const uint32_t* sorted_key, const int32_t* sorted_src,
+int ghf_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, void* stream) {
+    GHF_REQUIRE(h && h_split, "split3_rows: null pointer argument");
+    GHF_REQUIRE(N > 0 && d > 0 && d % 4 == 0 && row0 >= 0 && rows >= 0 && row0 + rows <= N, "split3_rows: bad shape or row range");
+    return launch_split3_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
+}
+
+int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d, const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg, const int32_t* chunk_tab,
                           const int32_t* blk_chunk_off, const int32_t* item_tab, const int32_t* blk_item_off,
                           int64_t item0, int64_t n_items, float* partial, int64_t E, int R, int block_nodes,
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0, int64_t rows,
-                          float* h_out, int flags, void* stream) {
+                          float* h_out, void* h_split_out, int flags, void* stream) {
     GHF_REQUIRE(h && sorted_key && sorted_src && seg_off && indeg && W_msg && bias && h_out,
                 "message_layer_fwd: null pointer argument");
     GHF_REQUIRE((flags & GHF_FLAG_NO_TAIL) || (ln_gamma && ln_beta), "message_layer_fwd: LayerNorm parameters missing");
@@ -111,9 +117,12 @@ int ghf_message_layer_fwd(const float* h, int64_t N, int d, const uint32_t* sort
     GHF_REQUIRE(row0 % block_nodes == 0, "message_layer_fwd: row0 must be a multiple of block_nodes");
     GHF_REQUIRE(block_nodes == 1 || (chunk_tab && blk_chunk_off && item_tab && blk_item_off && item0 >= 0 && n_items >= 0),
                 "message_layer_fwd: block plans need the chunk and item tables");
-    MsgArgs a{h, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, item0, n_items,
+    GHF_REQUIRE(wlayout != GHF_WLAYOUT_SPLIT3 || h_split, "message_layer_fwd: SPLIT3 weights need h_split (ghf_split3_rows)");
+    GHF_REQUIRE(!h_split_out || (wlayout == GHF_WLAYOUT_SPLIT3 && !(flags & GHF_FLAG_NO_TAIL) && h_split_out != h_split),
+                "message_layer_fwd: h_split_out needs SPLIT3 weights and the fused tail, and must not alias h_split");
+    MsgArgs a{h, h_split, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, item0, n_items,
               partial, E, R, block_nodes, W_msg, W_self, bias, wlayout,
-              ln_gamma, ln_beta, ln_eps, row0, rows, h_out, flags};
+              ln_gamma, ln_beta, ln_eps, row0, rows, h_out, h_split_out, flags};
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
     return launch_message_mfma(a, (hipStream_t)stream);

@@ -88,16 +88,26 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
 int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
                       float* h0, hipStream_t stream);
 
+// x = p[0] + p[1] + p[2] exactly, p[i] = the i-th group of 8 significand bits as a bf16 bit pattern (truncation)
+__device__ __forceinline__ void split3_pieces(float x, uint16_t (&p)[3]) {
+    const uint32_t u1 = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(u1 & 0xFFFF0000u);
+    const uint32_t u2 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u2 & 0xFFFF0000u);
+    p[0] = (uint16_t)(u1 >> 16); p[1] = (uint16_t)(u2 >> 16); p[2] = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
 struct MsgArgs {
-    const float* h; int64_t N; int d;
+    const float* h; const void* h_split; int64_t N; int d;
     const uint32_t* sorted_key; const int32_t* sorted_src; const int32_t* seg_off; const int32_t* indeg;
     const int32_t* chunk_tab; const int32_t* blk_chunk_off;
     const int32_t* item_tab; const int32_t* blk_item_off; int64_t item0; int64_t n_items; float* partial;
     int64_t E; int R; int block_nodes;
     const float* W_msg; const float* W_self; const float* bias; int wlayout;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
-    int64_t row0; int64_t rows; float* h_out; int flags;
+    int64_t row0; int64_t rows; float* h_out; void* h_split_out; int flags;
 };
+int launch_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
 int launch_message_generic(const MsgArgs& a, hipStream_t stream);
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
 int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)

@@ -89,21 +89,22 @@ struct SxChunk { int r; int e0; int rows; int cross; };     // rows == 0: none
 
 template <int D>
 __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kernel(
-    const float* __restrict__ h, int64_t N, const uint32_t* __restrict__ sorted_key,
+    const float* __restrict__ h, const void* __restrict__ h_split, int64_t N, const uint32_t* __restrict__ sorted_key,
     const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
     const int32_t* __restrict__ item_tab, int64_t item0, float* __restrict__ partial,
     const int32_t* __restrict__ indeg, int R,
     const void* __restrict__ Wsplit, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    int64_t row0, int64_t row_end, float* __restrict__ h_out, int no_tail, uint32_t w_bytes, int dbg_arg) {
+    int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail, uint32_t w_bytes,
+    int dbg_arg) {
 #ifdef GHF_ABLATE
-    const int dbg = dbg_arg;      // 1: gather one hot row, 2: one relation's weights, 4: no main MFMAs, 8: no scatter, 16: no B loads in the stream
+    const int dbg = dbg_arg;      // 1: gather one hot row, 2: one relation's weights, 4: no main MFMAs, 8: no scatter, 16: no B loads in the stream, 32: two B pieces / three products only
 #else
     constexpr int dbg = 0;
 #endif
     using C = SxCfg<D>;
     constexpr int BN = C::BN, MTC = C::MTC;
-    constexpr int NWV = 8, TW = 4;            // waves per workgroup, per team
+    constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
     constexpr int KS = D / 32;                // k-steps of 32 per phase (one bf16 MFMA deep)
     constexpr int NKS = 2 * KS;               // k-steps of the whole contraction [h_u | h_v]
     constexpr int NT = D / 16;                // 16-column fragments of the output
@@ -111,21 +112,23 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
     constexpr int ROWB = D * 2 + 16;          // bytes per row of one bf16 plane of the A tile: padded by one granule, so
                                               // that 16 rows x one granule cover all banks with plain immediate offsets
     constexpr int PLANE = 16 * MTC * ROWB;    // bytes per plane
-    constexpr int CPR = D / 4;                // 16-byte chunks per A row
-    constexpr int RPI = 256 / D;              // A rows per 1 KiB LDS-DMA wave-instruction
     constexpr int CR = 16 * MTC;              // rows per chunk
-    constexpr int IPW = CR / RPI / TW;        // LDS-DMA instructions per wave per stage (6)
-    static_assert(NTW * TW == NT && (NTW == 1 || NTW == 2) && CR % (RPI * TW) == 0 && MTC == 3, "bad tile config");
+    constexpr int GPR = D / 8;                // 16-byte granules (8 bf16) per row of a plane (16)
+    constexpr int RPW = 64 / GPR;             // rows of one plane per wave-instruction (4)
+    constexpr int IPW = 3 * MTC;              // 16-byte loads per producer lane per stage: piece i = (tile i / 3, plane i % 3)
+    constexpr int HROW = 3 * D * 2;           // bytes per node of h_split: [3 planes][D] bf16
+    static_assert(NTW * TW == NT && NTW == 2 && RPW * TW == 16 && MTC == 3, "bad tile config");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* acc_lds = (float*)smem;                    // [BN + 4][D]: block sums + 4 dummy rows
-    char* Abase = (char*)(acc_lds + (BN + 4) * D);    // [2 teams][3 planes][CR][D + 8] bf16
-    constexpr int MSTR = CR + 16;                     // ints of row words per team: CR rows, then one flag per row tile
-    int* s_meta = (int*)(Abase + 2 * 3 * PLANE);      // [2 teams][MSTR]: row words (target row << 4) | run head; tile flags: has a run > 1
+    char* Abase = (char*)(acc_lds + (BN + 4) * D);    // [2 stages][3 planes][CR][D + 8] bf16
+    constexpr int MSTR = CR + 16;                     // ints of row words per chunk: CR rows, then one run mask per row tile
+    int* s_meta = (int*)(Abase + 2 * 3 * PLANE);      // [2 chunks][MSTR]: row words (target row << 4) | run head; per tile: rows continuing a run
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int team = w >> 2, tw = w & 3;              // waves w and w+4 share a SIMD: one of each team per SIMD
+    const bool producer = w >= TW;                    // waves 4..7 stage the A tiles, waves 0..3 run the MFMAs and the sums;
+    const int tw = w & 3;                             // waves w and w+4 share a SIMD: one of each kind per SIMD
     const int q = lane >> 4, c16 = lane & 15;
     // work item: { block, first chunk, one past last chunk, scratch slot or -1 } (plan.hip); a heavy block (the hub
     // of a power-law graph) is several items, whose raw sums go to scratch slots and are combined by a second kernel
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
     const int64_t node0 = blk * BN;
     const int nrows = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
     const uint32_t seg0 = (uint32_t)(blk * R);
-    char* const Abuf = Abase + team * 3 * PLANE;      // this team's A tile
-    int* const meta = s_meta + team * MSTR;           // this team's row words
+    auto a_tile = [&](int s) -> char* { return Abase + (s & 1) * 3 * PLANE; };    // A tile of stage s (stage = 2*chunk + phase)
+    auto row_words = [&](int k) -> int* { return s_meta + (k & 1) * MSTR; };      // row words of the block's k-th chunk
 
     for (int i = tid; i < (BN + 4) * D / 4; i += NWV * 64) ((f32x4*)acc_lds)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < 2 * MSTR; i += NWV * 64) s_meta[i] = (i % MSTR) < CR ? ((BN + ((i >> 2) & 3)) * (D * 4)) | (i & 15) : 0;
@@ -167,89 +170,88 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
         return Words{*at<int>(sorted_src, eo), *at<int>(sorted_key, eo)};
     };
 
-    // Gather the (chunk, phase) A tile, register-staged as in message_pp.hip: the 16-byte fp32 loads are issued early
-    // in PREP (stage_load); at its end (stage_commit) every loaded f32x4 is cut into its three bf16 pieces and
-    // written, 8 bytes per plane, to this team's tile.  LDS image of a plane: rows linear (256 bytes), the sixteen
-    // 16-byte granules of a row XOR-swizzled by (row & 15) so that the MFMA fragment reads (16 rows x one granule)
-    // spread over all banks.  Phase 1 also publishes the chunk's row words: (byte offset of the row's target in the
-    // block sums) | run head.  Branch-free: all CR rows are gathered (pad rows repeat the last live row: an L2 hit).
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)h, 0, (int)(uint32_t)((uint64_t)N * D * 4), 0x00020000);
-    f32x4 stg[IPW];
-    auto stage_load = [&](const SxChunk& c, int ph, const Words& wd) {
+    // ---- producers -----------------------------------------------------------------------------------------------
+    // Gather one stage's A tile.  h_split holds every row of h already cut into its three bf16 pieces
+    // ([N][3 planes][D] bf16, ghf_split3_rows or the previous layer's tail), so a producer only moves bytes:
+    // 16-byte loads into registers (stage_load) and, one barrier interval later, 16-byte LDS writes (stage_commit).
+    // (Cutting the rows here cost ~130 vector-ALU instructions per lane and stage; the SIMD's issue slots, shared
+    // with the consumer wave's MFMA stream, were what bounded that kernel.)
+    // LDS image of a plane: rows of 256 + 16 bytes, so that an MFMA fragment read (16 rows x one 16-byte granule)
+    // covers all banks with plain immediate offsets.  Piece i of wave tw: plane i % 3 of rows 4*tw .. 4*tw+3 of row
+    // tile i / 3, 16 lanes per row; the pieces of dead tiles are skipped.
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)h_split, 0, (int)(uint32_t)((uint64_t)N * HROW), 0x00020000);
+    auto stage_load = [&](i32x4 (&stg)[IPW], const SxChunk& c, int ph, const Words& wd) {
         const uint32_t kbase = (seg0 + (uint32_t)c.r) * (uint32_t)BN;
-        if (ph == 1 && tw == 0) {
-            const int head = (int)((uint32_t)wd.src >> SRC_BITS), row16 = lane & 15;
-            const bool live = lane < c.rows;
-            const int tgt = (live && head == row16) ? (int)((uint32_t)wd.key - kbase) : BN + ((lane >> 2) & 3);
-            const unsigned long long runs = __ballot(live && head != row16);      // rows that continue a run
-            if (lane < CR) meta[lane] = (tgt * (D * 4)) | (live ? head : row16);  // D*4 = 512: the low 4 bits stay free
-            if (lane < MTC) meta[CR + lane] = (int)((runs >> (16 * lane)) & 0xFFFFull);
-        }
-        const int mts = (c.rows + 15) >> 4;                                // live row tiles: pieces of dead tiles are skipped
+        const int mts = (c.rows + 15) >> 4;                                // live row tiles
         const int word = ph == 0 ? wd.src : wd.key;
-        int v[IPW];
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) v[i] = __shfl(word, (i * TW + tw) * RPI + lane / CPR, 64);
-        PP_STAMP(5);                                    // prep: row words + shuffles
         const uint32_t nbase = ph == 0 ? 0u : (uint32_t)node0 - kbase;
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            if (i / 2 >= mts) continue;                                    // piece i holds rows of tile i/2 only (see stage_commit)
-            uint32_t node = (ph == 0 ? (uint32_t)(v[i] & SRC_MASK) : (uint32_t)v[i]) + nbase;
+        for (int m = 0; m < MTC; ++m) {
+            if (m >= mts) continue;
+            const int v = __shfl(word, m * 16 + tw * RPW + lane / GPR, 64);
+            uint32_t node = (ph == 0 ? (uint32_t)(v & SRC_MASK) : (uint32_t)v) + nbase;
             if (dbg & 1) node = (uint32_t)node0;
-            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsH, (int)(node * (uint32_t)(D * 4)) + ((lane % CPR) << 4), 0, 0));
+            const int off = (int)(node * (uint32_t)HROW) + ((lane % GPR) << 4);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) stg[m * 3 + pl] = __builtin_amdgcn_raw_buffer_load_b128(rsH, off + pl * (D * 2), 0, 0);
         }
-        PP_STAMP(7);                                    // prep: gather issue
     };
-    auto stage_commit = [&](int mts) {
-        const int k4 = lane % CPR;                                         // which f32x4 of the row: elements 4*k4 .. +3
-        static_assert(TW * RPI * 2 == 16 && IPW == 2 * MTC, "piece i of every wave must lie in row tile i / 2");
+    auto stage_commit = [&](const i32x4 (&stg)[IPW], char* Abuf, int rows) {
+        const int mts = (rows + 15) >> 4;
+        char* dst = Abuf + (tw * RPW + lane / GPR) * ROWB + ((lane % GPR) << 4);
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            if (i / 2 >= mts) continue;
-            const int rho = (i * TW + tw) * RPI + lane / CPR;              // tile row this lane fills: rows interleaved over the waves
-            char* dst = Abuf + rho * ROWB + (k4 << 3);
-            i32x2 pc[3];
-            split3(stg[i], pc);
+        for (int m = 0; m < MTC; ++m) {
+            if (m >= mts) continue;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *(i32x2*)(dst + pl * PLANE) = pc[pl];
+            for (int pl = 0; pl < 3; ++pl) *(i32x4*)(dst + m * 16 * ROWB + pl * PLANE) = stg[m * 3 + pl];
         }
+    };
+    // a chunk's row words for the consumers' scatter: (byte offset of the row's target in the block sums) | run head,
+    // and per row tile the mask of rows that continue a run of equal destinations
+    auto publish_rows = [&](const SxChunk& c, const Words& wd, int* meta) {
+        if (tw != 0) return;
+        const uint32_t kbase = (seg0 + (uint32_t)c.r) * (uint32_t)BN;
+        const int head = (int)((uint32_t)wd.src >> SRC_BITS), row16 = lane & 15;
+        const bool live = lane < c.rows;
+        const int tgt = (live && head == row16) ? (int)((uint32_t)wd.key - kbase) : BN + ((lane >> 2) & 3);
+        const unsigned long long runs = __ballot(live && head != row16);
+        if (lane < CR) meta[lane] = (tgt * (D * 4)) | (live ? head : row16);  // D*4 = 512: the low 4 bits stay free
+        if (lane < MTC) meta[CR + lane] = (int)((runs >> (16 * lane)) & 0xFFFFull);
     };
 
+    // ---- consumers -----------------------------------------------------------------------------------------------
     // B fragments (GHF_WLAYOUT_SPLIT3, written by K1): Wsplit[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8]
-    // bf16, kk in [0, 2d).  Byte offset of piece 0 of k-step 0 of (relation r, phase ph) for this wave's fragment t:
-    // Buffer loads: resource descriptor + scalar offset (relation, fragment, k-step) + lane*16 + immediate (piece), so
-    // one VGPR addresses them all (with plain pointers hipcc kept a 64-bit VGPR address per fragment and k-step).
+    // bf16, kk in [0, 2d).  Buffer loads: resource descriptor + scalar offset (relation, fragment, k-step) + lane*16 +
+    // immediate (piece), so one VGPR addresses them all.
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wsplit, 0, (int)w_bytes, 0x00020000);
     auto b_soff = [&](int r, int ph, int t) -> int {
         if (dbg & 2) r = 0;
         return __builtin_amdgcn_readfirstlane((((r * NT + tw * NTW + t) * NKS + ph * KS) * 3) * 1024);
     };
     const int lane16 = lane * 16;
-    constexpr int BRING = 3;                           // = BPRE + 1 (declared below)
-    constexpr int BPRE = 2;                            // k-steps of B requested ahead (end of my previous interval); the rest just in time
-    auto load_b_head = [&](int r, int ph, i32x4 (&b)[BRING][NTW][3]) {
+    // ring of BRING = BPRE + 1 k-steps of B pieces: k-step j of a stage sits in slot j % BRING.  A slot is refilled
+    // (for k-step j + BPRE, or at the end of a stage for the next stage's head) only after the MFMAs of the k-step it
+    // held have been issued.
+    constexpr int BPRE = 2, BRING = BPRE + 1;
+    i32x4 b[BRING][NTW][3];
+    auto load_b_head = [&](int r, int ph) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int j = 0; j < BPRE; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) b[j % BRING][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * 3072, 0);
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (pl == 2 && (dbg & 32)) continue;
+                    b[j % BRING][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * 3072, 0);
+                }
     };
 
     f32x4 acc[MTC][NTW];
-    // ring of BRING = BPRE + 1 k-steps of B pieces: k-step j of a phase sits in slot j % BRING.  A slot is refilled
-    // (for k-step j + BPRE, or at the end of the interval for the next phase's head) only after the MFMAs of the
-    // k-step it held have been issued.
-    i32x4 b[BRING][NTW][3];
-
-    // MFMA interval: one K-phase of the chunk = KS k-steps of 32; M = live row tiles (compile-time per variant).
-    // Per (k-step, row tile): 3 A-piece fragments from LDS (read one step ahead), and for each of the wave's column
-    // fragments the six piece products, smallest first.  B pieces of k-step j+BPRE are requested while k-step j
-    // computes (message_pp.hip: a load issued from inside the MFMA stream is cheap, one issued by the SIMD partner
-    // beside it is not).
-    auto compute_tiles = [&](int mt, int r, int ph) {
-        constexpr int M = MTC;                          // one code path; dead row tiles (m >= mt) skip their MFMAs
+    // One stage = one K-phase of the chunk = KS k-steps of 32.  Per (k-step, row tile): 3 A-piece fragments from LDS
+    // (read one step ahead), and for each of the wave's column fragments the six piece products, smallest first.
+    // B pieces of k-step j+BPRE are requested while k-step j computes.  One code path: dead row tiles (m >= mt) skip
+    // their MFMAs (three tile-count variants of this loop cost 80 spilled registers).
+    auto compute_stage = [&](int mt, int r, int ph, const char* Abuf) {
         int bs[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) bs[t] = b_soff(r, ph, t);
@@ -266,44 +268,47 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if (pl == 2 && (dbg & 32)) continue;
                         b[(j + BPRE) % BRING][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, bs[t] + (j + BPRE) * 3072, 0);
+                    }
             }
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const int cur = (j * M + m) & 1;
-                if (j * M + m + 1 < KS * M) lda((j * M + m + 1) / M, (j * M + m + 1) % M, a[cur ^ 1]);
+            for (int m = 0; m < MTC; ++m) {
+                const int cur = (j * MTC + m) & 1;
+                if (j * MTC + m + 1 < KS * MTC) lda((j * MTC + m + 1) / MTC, (j * MTC + m + 1) % MTC, a[cur ^ 1]);
                 if (m < mt && !(dbg & 4)) {
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    auto fma = [&](int pa, int pb) {
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][pa]),
-                                                                            __builtin_bit_cast(bf16x8, b[j % BRING][t][pb]),
-                                                                            acc[m][t], 0, 0, 0);
-                    };
-                    fma(2, 0); fma(0, 2); fma(1, 1);                        // weight 2^-16
-                    fma(1, 0); fma(0, 1);                                   // weight 2^-8
-                    fma(0, 0);                                              // weight 1
-                }
+                    for (int t = 0; t < NTW; ++t) {
+                        auto fma = [&](int pa, int pb) {
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][pa]),
+                                                                                __builtin_bit_cast(bf16x8, b[j % BRING][t][pb]),
+                                                                                acc[m][t], 0, 0, 0);
+                        };
+                        if (!(dbg & 32)) { fma(2, 0); fma(0, 2); fma(1, 1); }  // weight 2^-16
+                        fma(1, 0); fma(0, 1);                               // weight 2^-8
+                        fma(0, 0);                                          // weight 1
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // PREP: segment-sum finished rows by destination into this wave's column strips, tiles [M0, M1).
-    // x = the rows (acc, or the copy kept for the deferred tile), mq = their row words.
-    // live = row tiles of the chunk; runs = per-tile masks of rows that continue a run of equal destinations: a tile
-    // without any is its own segment sum, and skips the MFMAs.
-    auto scatter_tiles = [&](auto M0tag, auto M1tag, f32x4 (&x)[MTC][NTW], const i32x4 (&mq)[MTC], int live, const i32x4& runs) {
-        constexpr int M0 = decltype(M0tag)::value, M1 = decltype(M1tag)::value;
-        const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16 * NTW);   // NTW == 2: interleaved
-        // plain LDS read-add-write through inline asm (see message_mfma.hip), tile by tile: a run of equal
-        // destinations may continue into the next tile.  With two fragments per wave (D = 128) the block sums keep a
-        // wave's 32 columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column 32*tw + 16*t + c16; the tail
-        // undoes it), so a lane's two values are adjacent and move with one 64-bit LDS access.
+    // Segment-sum the finished rows by destination into this wave's column strips.  live = row tiles of the chunk;
+    // a tile without a run of equal destinations is its own segment sum and skips the MFMAs.  Then a plain LDS
+    // read-add-write through inline asm (see message_mfma.hip), tile by tile: a run may continue into the next tile.
+    // The block sums keep a wave's 32 columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column
+    // 32*tw + 16*t + c16; the tail undoes it), so a lane's two values are adjacent and move with one 64-bit access.
+    auto scatter_chunk = [&](int live, const int* meta) {
+        static_assert(NTW == 2, "two column fragments per wave");
+        const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16 * NTW);
+        i32x4 mq[MTC];
 #pragma unroll
-        for (int m = M0; m < M1; ++m) {
+        for (int m = 0; m < MTC; ++m) mq[m] = *(const i32x4*)(meta + m * 16 + 4 * q);
+        const i32x4 runs = *(const i32x4*)(meta + CR);
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) {
             if (m >= live) continue;
             f32x4 y[NTW];
             if (__builtin_amdgcn_readfirstlane(runs[m])) {
@@ -314,16 +319,15 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
                     const float sel = ((mq[m][s] & 15) == c16) ? 1.0f : 0.0f;   // S[i = c16][k = 4q + s] = (head(k) == i)
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)
-                        y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, x[m][t][s], y[t], 0, 0, 0);
+                        y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, acc[m][t][s], y[t], 0, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) y[t] = x[m][t];
+                for (int t = 0; t < NTW; ++t) y[t] = acc[m][t];
             }
             unsigned addr[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) addr[s] = strip + ((unsigned)mq[m][s] & ~15u);           // the run's target row, or a dummy
-            static_assert(NTW == 2, "two column fragments per wave");
             f32x2 v[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) asm volatile("ds_read_b64 %0, %1" : "=v"(v[s]) : "v"(addr[s]) : "memory");
@@ -335,150 +339,84 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
             }
         }
     };
-    auto load_row_words = [&](i32x4 (&mq)[MTC], i32x4& runs) {
-#pragma unroll
-        for (int m = 0; m < MTC; ++m) mq[m] = *(const i32x4*)(meta + m * 16 + 4 * q);
-        runs = *(const i32x4*)(meta + CR);
-    };
 
-    // ---- team state --------------------------------------------------------------------------------------------
-    int kc = c_begin + team;                           // index of my current chunk `ch`
-    SxChunk ch = decode(load_desc(kc), kc);
-    SxChunk ch_next{0, 0, 0, 0};
-    i32x2 d_next = load_desc(kc + 2);
-    Words wd{0, 0}, wd_next{0, 0};                     // plan words of `ch` / of my next chunk
-    float bias_v[NTW] = {};
-    int pending = 0;                                   // live row tiles of my finished, not yet scattered chunk
+    __syncthreads();                                   // sums zeroed, row words initialised
+    PP_STAMP(-1);
 
-    // The scatter of a finished chunk is split over my next two PREPs so that neither exceeds the partner's MFMA
-    // interval (a PREP instruction gets about one issue slot per partner MFMA): tiles 0..1 in the phase-0 PREP,
-    // tile 2 — rows and row words copied to registers there — in the phase-1 PREP.
-    f32x4 x2[MTC][NTW];                                // only [MTC-1] is used: the deferred tile's rows
-    i32x4 mq2[MTC];                                    // only [MTC-1] is used: its row words
-    int deferred = 0;
-    int runs2 = 0;                                     // the deferred tile's run mask
-
-    // PREP before a phase-0 MFMA interval: move to my next chunk and request what its phase 0 needs FIRST, then
-    // scatter (part of) the chunk that just finished while those loads are in flight.
-    auto prep_ph0 = [&]() {
-        __builtin_amdgcn_s_setprio(3);                  // PREP is short, latency-critical work beside the partner's MFMA stream
-        const int pend = pending;
-        if (pend) {
-            pending = 0;
-            ch = ch_next;                              // decoded, and its words loaded, in my previous PREP
-            wd = wd_next;
-            kc += 2;
+    // Two programs, 2*nchunks + 1 barriers each.  Barrier interval s belongs to stage s:
+    //   consumers:  MFMAs of stage s from A tile s & 1; after a chunk's phase 1, its bias and its scatter
+    //   producers:  request the gather of stage s + 2 into registers, then cut the rows of stage s + 1 (requested one
+    //               interval ago) into the other A tile: a gather has a whole interval to arrive
+    if (producer) {
+        i32x4 stgA[IPW], stgB[IPW];                    // phase-0 / phase-1 stages in flight
+        SxChunk chI = decode(load_desc(c_begin), c_begin), chN = decode(load_desc(c_begin + 1), c_begin + 1);
+        i32x2 dNN = load_desc(c_begin + 2);
+        Words wdI{0, 0}, wdN{0, 0};
+        if (chI.rows) {
+            wdI = load_words(chI);
+            if (chN.rows) wdN = load_words(chN);
+            stage_load(stgA, chI, 0, wdI);
+            stage_load(stgB, chI, 1, wdI);
+            stage_commit(stgA, a_tile(0), chI.rows);
         }
-        const bool staged = ch.rows != 0;
-        if (staged) {
-            stage_load(ch, 0, wd);
+        for (int k = 0; k < nchunks; ++k) {            // chI = chunk k, chN = chunk k + 1
+            __syncthreads();                           // interval 2k
+            PP_STAMP(0);
+            if (chN.rows) stage_load(stgA, chN, 0, wdN);
+            PP_STAMP(2);
+            stage_commit(stgB, a_tile(1), chI.rows);
+            publish_rows(chI, wdI, row_words(k));
+            PP_STAMP(3);
+            __syncthreads();                           // interval 2k + 1
+            PP_STAMP(0);
+            if (chN.rows) {
+                stage_load(stgB, chN, 1, wdN);
+                PP_STAMP(2);
+                stage_commit(stgA, a_tile(0), chN.rows);
+            }
+            chI = chN;
+            wdI = wdN;
+            chN = decode(dNN, c_begin + k + 2);
+            if (chN.rows) wdN = load_words(chN);
+            dNN = load_desc(c_begin + k + 3);
+            PP_STAMP(3);
+        }
+        __syncthreads();
+    } else {
+        SxChunk ch = decode(load_desc(c_begin), c_begin);
+        i32x2 dn = load_desc(c_begin + 1);
+        float bias_v[NTW] = {};
+        if (ch.rows) load_b_head(ch.r, 0);
+        for (int k = 0; k < nchunks; ++k) {
+            const int mt = (ch.rows + 15) >> 4;
+            __syncthreads();                           // interval 2k: phase 0
+            PP_STAMP(0);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) bias_v[t] = *at<float>(bias, (uint32_t)(ch.r * D + (tw * NTW + t) * 16 + c16) * 4u);
-            d_next = load_desc(kc + 2);
-        }
-        asm volatile("" ::: "memory");
-        PP_STAMP(2);                                    // prep: issue
-        if (pend) {                                    // consumes registers and LDS only: nothing just requested
-            i32x4 mq[MTC], runs;
-            load_row_words(mq, runs);
-            if (!(dbg & 8)) scatter_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, MTC - 1>{}, acc, mq, pend, runs);
-            mq2[MTC - 1] = mq[MTC - 1];
-            runs2 = runs[MTC - 1];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) x2[MTC - 1][t] = acc[MTC - 1][t];
-            deferred = pend == MTC;                    // a dead last tile carries zeros into dummy rows: skip it
-        }
-        PP_STAMP(3);                                    // prep: scatter
-        if (staged) stage_commit((ch.rows + 15) >> 4);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_waitcnt(SX_WAIT_VMCNT0);     // everything landed before the barrier that hands it over
-        PP_STAMP(4);                                    // prep: wait for memory + LDS commit
-    };
-    // PREP before a phase-1 MFMA interval
-    auto prep_ph1 = [&]() {
-        __builtin_amdgcn_s_setprio(3);
-        const bool staged = ch.rows != 0;
-        if (staged) {
-            stage_load(ch, 1, wd);
-            ch_next = decode(d_next, kc + 2);          // loaded one PREP ago
-            if (ch_next.rows) wd_next = load_words(ch_next);
-        }
-        PP_STAMP(2);
-        if (deferred) {
-            if (!(dbg & 8)) scatter_tiles(std::integral_constant<int, MTC - 1>{}, std::integral_constant<int, MTC>{}, x2, mq2, MTC, (i32x4){0, 0, runs2, 0});
-            deferred = 0;
-        }
-        PP_STAMP(3);
-        if (staged) stage_commit((ch.rows + 15) >> 4);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_waitcnt(SX_WAIT_VMCNT0);
-        PP_STAMP(4);
-    };
-    auto mfma_phase = [&](int ph) {
-        PP_STAMP(0);                                    // barrier wait
-        if (!ch.rows) return;
-        const int mt = (ch.rows + 15) >> 4;
-        if (ph == 0) {
 #pragma unroll
             for (int m = 0; m < MTC; ++m)
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        compute_tiles(mt, ch.r, ph);
-        if (ph == 1) {                                 // finish the rows: bias[r] once per edge row; dead tiles -> zeros
+            compute_stage(mt, ch.r, 0, a_tile(0));
+            load_b_head(ch.r, 1);
+            PP_STAMP(1);
+            __syncthreads();                           // interval 2k + 1: phase 1, then the chunk's rows join the sums
+            PP_STAMP(0);
+            compute_stage(mt, ch.r, 1, a_tile(1));
+            const SxChunk nx = decode(dn, c_begin + k + 1);
+            if (nx.rows) load_b_head(nx.r, 0);         // lands during the scatter
+            dn = load_desc(c_begin + k + 2);
+            PP_STAMP(1);
 #pragma unroll
             for (int m = 0; m < MTC; ++m)
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[m][t] = m < mt ? acc[m][t] + bias_v[t] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            pending = mt;
+                for (int t = 0; t < NTW; ++t) acc[m][t] = acc[m][t] + bias_v[t];   // bias[r] once per edge row
+            if (!(dbg & 8)) scatter_chunk(mt, row_words(k));
+            ch = nx;
+            PP_STAMP(4);
         }
-        // the first B fragments of my NEXT step, requested here at the end of my interval (my SIMD partner is in
-        // PREP, no MFMA stream to compete with); they land during my own PREP, which ends with vmcnt(0)
-        if (ph == 0) load_b_head(ch.r, 1, b);
-        else if (ch_next.rows) load_b_head(ch_next.r, 0, b);
-        PP_STAMP(1);                                    // mfma interval
-    };
-
-    if (ch.rows) {
-        wd = load_words(ch);
-        load_b_head(ch.r, 0, b);
+        __syncthreads();
     }
-    __syncthreads();                                   // sums zeroed, row words initialised
-    PP_STAMP(-1);
-
-    // Two static programs, one per team, offset by one barrier interval; both execute 4*iters + 1 barriers.
-    //   interval:   4i        4i+1      4i+2      4i+3
-    //   team 0:     MFMA ph0  PREP ph1  MFMA ph1  PREP ph0 (scatter + next chunk)
-    //   team 1:     PREP ph0  MFMA ph0  PREP ph1  MFMA ph1
-    const int iters = (nchunks + 1) >> 1;              // team 0 never has fewer chunks than team 1
-    if (team == 0) {
-        prep_ph0();
-        for (int it = 0; it < iters; ++it) {
-            __syncthreads();  mfma_phase(0);
-            __syncthreads();  PP_STAMP(0); prep_ph1();
-            __syncthreads();  mfma_phase(1);
-            __syncthreads();  PP_STAMP(0); prep_ph0();
-        }
-    } else {
-        for (int it = 0; it < iters; ++it) {
-            __syncthreads();  PP_STAMP(0); prep_ph0();
-            __syncthreads();  mfma_phase(0);
-            __syncthreads();  PP_STAMP(0); prep_ph1();
-            __syncthreads();  mfma_phase(1);
-        }
-    }
-    // drain, one team per interval (their read-add-writes must not overlap): team 0's deferred tile, then team 1's
-    // last chunk
-    __syncthreads();
-    if (team == 0 && deferred)
-        scatter_tiles(std::integral_constant<int, MTC - 1>{}, std::integral_constant<int, MTC>{}, x2, mq2, MTC, (i32x4){0, 0, runs2, 0});
-    __syncthreads();
-    if (team == 1 && pending) {
-        i32x4 mq[MTC], runs;
-        load_row_words(mq, runs);
-        scatter_tiles(std::integral_constant<int, 0>{}, std::integral_constant<int, MTC>{}, acc, mq, pending, runs);
-    }
-    __syncthreads();
 
     // ---- fused tail: one wave per destination row, RB rows in flight -----------------------------------------
     constexpr int CPL = D / 64;
@@ -536,6 +474,16 @@ __global__ __launch_bounds__(512, SxCfg<D>::WAVES_PER_SIMD) void message_sx_kern
             if (v < nrows) {
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + v) * D + col[c]] = x[rb][c];
+                if (h_split_out) {                     // the same rows cut into bf16 pieces, for the next layer's gathers
+                    uint16_t* __restrict__ sp = (uint16_t*)h_split_out + (size_t)(node0 + v) * (3 * D);
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        uint16_t pc[3];
+                        split3_pieces(x[rb][c], pc);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) sp[pl * D + col[c]] = pc[pl];
+                    }
+                }
             }
         }
     }
@@ -564,13 +512,38 @@ static int launch_sx_for(const MsgArgs& a, hipStream_t stream) {
     GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_sx_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(sx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(sx): split blocks need the `partial` scratch");
-    message_sx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
+    GHF_REQUIRE(a.h_split, "message(sx): h_split is missing");
+    GHF_REQUIRE((uint64_t)a.N * D * 6 < (1ull << 32), "message(sx): N*d*6 must stay below 4 GiB");
+    message_sx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
                                                                    a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
-                                                                   a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out,
+                                                                   a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
                                                                    (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0,
                                                                    (uint32_t)((uint64_t)a.R * 2 * D * D * 6), dbg);
     GHF_LAUNCH_CHECK();
     if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
+    return GHF_OK;
+}
+
+// ghf_split3_rows: one thread per 4 consecutive elements of a row
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ h, int64_t row0, int64_t rows, int d,
+                                                          char* __restrict__ out) {
+    const int q4 = d >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * q4) return;
+    const int64_t row = row0 + i / q4;
+    const int k4 = (int)(i % q4);
+    i32x2 pc[3];
+    split3(*(const f32x4*)(h + row * d + 4 * k4), pc);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *(i32x2*)(out + row * (6 * (int64_t)d) + pl * 2 * d + k4 * 8) = pc[pl];
+}
+
+int launch_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream) {
+    if (rows <= 0) return GHF_OK;
+    const int64_t n = rows * (d >> 2);
+    GHF_REQUIRE(cdiv(n, 256) < (1ll << 31), "split3_rows: too many rows per launch");
+    split3_rows_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(h, row0, rows, d, (char*)h_split);
+    GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
 

@@ -67,13 +67,6 @@ __device__ __forceinline__ size_t split3_index(int r, int kk, int o, int d) {   
     const int NT = d >> 4, NKS = d >> 4;
     return ((((size_t)r * NT + (o >> 4)) * NKS + (kk >> 5)) * 3 * 64 + (((kk & 31) >> 3) << 4) + (o & 15)) * 8 + (kk & 7);
 }
-__device__ __forceinline__ void split3_pieces(float x, uint16_t (&p)[3]) {
-    const uint32_t u1 = __float_as_uint(x);
-    const float r1 = x - __uint_as_float(u1 & 0xFFFF0000u);
-    const uint32_t u2 = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(u2 & 0xFFFF0000u);
-    p[0] = (uint16_t)(u1 >> 16); p[1] = (uint16_t)(u2 >> 16); p[2] = (uint16_t)(__float_as_uint(r2) >> 16);
-}
 
 // Vector-ALU last layer: one wave per output element n (lanes stride K), looping relations.
 // grid (ceil(n_out / 4)), block 256 (4 waves).

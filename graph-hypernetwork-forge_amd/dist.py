@@ -85,11 +85,15 @@ class NativeOps:
     def layer_weights(self, model, l: int, text_embs, plan):
         return model.weight_generators[l].generate(text_embs, plan.wlayout)
 
-    def layer_rows(self, model, l: int, weights, h, plan, h_out, lo: int, hi: int) -> None:
+    def split_rows(self, plan, h):
+        """What the message kernel gathers: h itself, or its rows cut into bf16 pieces (SPLIT3 kernels)."""
+        return _native.split3_rows(h) if plan.wlayout == _native.WLAYOUT_SPLIT3 else None
+
+    def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int) -> None:
         norm = model.layer_norms[l]
         W, W_self, bias = weights
         _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(), norm.bias.detach(),
-                                  norm.eps, h_out, row0=lo, rows=hi - lo)
+                                  norm.eps, h_out, row0=lo, rows=hi - lo, h_split=h_split)
 
 
 class ShardedHyperGNN:
@@ -172,7 +176,9 @@ class ShardedHyperGNN:
         for l in range(model.num_layers):
             weights = self.ops.layer_weights(model, l, text_embs, plan)
             src, dst = h, h_next
-            self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], plan, dst[:N], lo, hi))
+            src_split = self.ops.split_rows(plan, src[:N])          # all rows are in place after the previous exchange
+            self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], src_split, plan,
+                                                                            dst[:N], lo, hi))
             h, h_next = h_next, h
         return h[:N]
 

@@ -127,13 +127,23 @@ class HyperGNN(nn.Module):
         h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach())
         h_next = torch.empty_like(h)
         lo, hi = plan.row_lo, (plan.row_hi or plan.N)
-        for gen, norm in zip(self.weight_generators, self.layer_norms):
+        # SPLIT3 kernels gather rows already cut into bf16 pieces; a layer's tail emits them for the next layer
+        split = plan.wlayout == _native.WLAYOUT_SPLIT3
+        hs = _native.split3_rows(h) if split else None
+        hs_next = torch.empty_like(hs) if split else None
+        last = len(self.weight_generators) - 1
+        for l, (gen, norm) in enumerate(zip(self.weight_generators, self.layer_norms)):
             W, W_self, bias = gen.generate(text_embs, plan.wlayout)
+            fused = split and exchange is None and l < last
             _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(),
-                                      norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo)
+                                      norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo,
+                                      h_split=hs, h_split_out=hs_next if fused else None)
             if exchange is not None:
                 exchange(h_next)
+                if split and l < last:
+                    _native.split3_rows(h_next, out=hs_next)
             h, h_next = h_next, h
+            hs, hs_next = hs_next, hs
         return h
 
     # -- reference-internal seam kept for API parity (reference :160-230) ---------------------

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 3
+#define GHF_ABI_VERSION 4
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -117,8 +117,11 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
  * same N, E, R, block_nodes; W/bias from ghf_weightgen_fwd with `wlayout`.
  * item0 / n_items: the work items of the blocks of the row range, i.e. blk_item_off[row0/BN] and
  * blk_item_off[ceil((row0+rows)/BN)] - item0 (host copies of two plan words); partial: scratch of
- * status[2]*BN*d floats for the split blocks (may be NULL when status[2] == 0). */
-int ghf_message_layer_fwd(const float* h /* [N,d] */, int64_t N, int d,
+ * status[2]*BN*d floats for the split blocks (may be NULL when status[2] == 0).
+ * h_split: the rows of h cut into bf16 pieces by ghf_split3_rows (or by a previous call's h_split_out); required
+ * when wlayout == GHF_WLAYOUT_SPLIT3, ignored otherwise.  h_split_out (optional, SPLIT3 only, not with
+ * GHF_FLAG_NO_TAIL): receives the split form of the h_out rows written by this call, for the next layer. */
+int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* [N][3][d] bf16 or NULL */, int64_t N, int d,
                           const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg,
                           const int32_t* chunk_tab, const int32_t* blk_chunk_off,
@@ -127,8 +130,13 @@ int ghf_message_layer_fwd(const float* h /* [N,d] */, int64_t N, int d,
                           int64_t E, int R, int block_nodes,
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps,
-                          int64_t row0, int64_t rows, float* h_out /* [N,d] */, int flags,
-                          void* stream);
+                          int64_t row0, int64_t rows, float* h_out /* [N,d] */,
+                          void* h_split_out /* [N][3][d] bf16 or NULL */, int flags, void* stream);
+
+/* Rows [row0, row0+rows) of h [N,d] cut exactly into three bf16 pieces each (x = p0 + p1 + p2: 8 + 8 + 8 significand
+ * bits, by truncation): h_split[v][piece][k] bf16, 6*d bytes per row.  This is what the SPLIT3 message kernel gathers
+ * (the split is done once per row here instead of once per edge there).  d % 4 == 0. */
+int ghf_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, void* stream);
 
 /* ---- K3 alone -------------------------------------------------------------------------
  * Replaces models/hypergnn.py:288-296 on rows [row0,row0+rows): agg already holds

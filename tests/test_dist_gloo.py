@@ -50,7 +50,10 @@ class OracleOps:
         d = model.hidden_dim
         return O.weight_generator(self._params(model), f"weight_generators.{l}.", text_embs, d, d)
 
-    def layer_rows(self, model, l, w, h, plan, h_out, lo, hi):
+    def split_rows(self, plan, h):
+        return None
+
+    def layer_rows(self, model, l, w, h, h_split, plan, h_out, lo, hi):
         p = self._params(model)
         agg = O.message_passing_factorised(h, plan.ei, plan.rel, w["W_msg"], w["W_self"], w["bias"])
         out = O.layer_tail(agg, h, p[f"layer_norms.{l}.weight"], p[f"layer_norms.{l}.bias"])

@@ -159,6 +159,27 @@ def test_split3_layout_is_an_exact_three_piece_cut_of_natural():
     assert np.array_equal((_bf16_np(p[0]) + _bf16_np(p[1])) + _bf16_np(p[2]), np.concatenate([Wm, Ws], axis=1))
 
 
+def test_split3_rows_and_the_fused_tail_agree():
+    """ghf_split3_rows is the exact 3-piece cut, and a layer's h_split_out equals split3_rows of its h_out."""
+    d, N, E, R = 128, 3000, 30000, 16
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=77, kind="uniform")
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    h_d = t(h)
+    hs = _native.split3_rows(h_d)
+    want = np.stack(_split3_np(h), axis=1)                                                # [N, 3, d] uint16
+    assert np.array_equal(hs.cpu().numpy().view(np.uint16), want)
+    part = torch.zeros_like(hs)
+    _native.split3_rows(h_d, out=part, row0=100, rows=50)
+    assert torch.equal(part[100:150], hs[100:150]) and not part[:100].any() and not part[150:].any()
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    assert plan.wlayout == _native.WLAYOUT_SPLIT3
+    W = _pack_weights(plan, Wm, Ws)[0]
+    out, out_split = torch.empty_like(h_d), torch.zeros_like(hs)
+    _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, out, h_split=hs,
+                              h_split_out=out_split)
+    assert torch.equal(out_split, _native.split3_rows(out))
+
+
 def _pack_weights(plan, Wm, Ws):
     """(W, W_self) device tensors in the layout the plan's kernel reads."""
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731

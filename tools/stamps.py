@@ -46,10 +46,14 @@ st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
 nw = d // 16
 st = st[:, :nw]
 tot = st.sum(axis=2)
+sx = plan.wlayout == _native.WLAYOUT_SPLIT3
 if lockstep:
     names = ["mem wait", "barrier", "prefetch issue", "compute", "scatter", "bookkeeping", "tail", "-"]
+elif sx:   # producer / consumer kernel (message_sx.hip): waves 0-3 consume, 4-7 produce
+    names = ["barrier wait", "consumer: mfma stage", "producer: gather issue", "producer: split+commit", "consumer: bias+scatter", "-", "drain+tail", "-"]
 else:   # ping-pong kernel (message_pp.hip)
     names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: gather issue"]
-print(f"blocks={nb} waves/block={nw} mean cycles per wave (100 MHz s_memtime ticks? see guide) = {tot.mean():.0f}")
+print(f"blocks={nb} waves/block={nw} mean cycles per wave = {tot.mean():.0f}")
+g0, g1 = ("consumers", "producers") if sx else ("team0", "team1")
 for i, n in enumerate(names[:8]):
-    print(f"  {n:22s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}   team0 {st[:, :4, i].mean():10.0f}  team1 {st[:, 4:, i].mean():10.0f}")
+    print(f"  {n:24s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}   {g0} {st[:, :4, i].mean():10.0f}  {g1} {st[:, 4:, i].mean():10.0f}")
