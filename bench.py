@@ -164,13 +164,15 @@ def main():
             W, W_self, bias = model.weight_generators[0].generate(te, plan.wlayout)
             h = _native.input_proj_fwd(x, model.input_proj.weight, model.input_proj.bias)
         h_out = torch.empty_like(h)
+        # kernels that gather pre-split rows get them as in the forward (made by the previous layer's tail)
+        hs = _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
         ln = model.layer_norms[0]
         slots = [(0, N)] if world == 1 else runner._spec.owned()     # this rank's destination rows
 
         def msg():
             for lo, hi in slots:
                 _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, ln.weight, ln.bias, ln.eps, h_out,
-                                          row0=lo, rows=hi - lo)
+                                          row0=lo, rows=hi - lo, h_split=hs)
         for _ in range(2):
             msg()
         torch.cuda.synchronize()

@@ -26,6 +26,8 @@ SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 2
 WLAYOUT_NATURAL = 0
 WLAYOUT_FRAG16 = 1
 WLAYOUT_SPLIT3 = 2          # bf16 B fragments, 3 exact pieces per weight (6 bytes each) in an opaque float32 buffer
+WLAYOUT_SPLIT2H = 3         # fp16 B fragments, 2 pieces per weight scaled by a power of two per relation (+ the scales)
+SPLIT_LAYOUTS = (WLAYOUT_SPLIT3, WLAYOUT_SPLIT2H)   # layouts whose kernels gather pre-split rows (split_rows)
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -45,7 +47,9 @@ SIGNATURES = {
     "ghf_message_layer_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
                                      _vp, _vp, _vp, _i32,
                                      _vp, _vp, _f32, _i64, _i64, _vp, _vp, _i32, _vp]),
-    "ghf_split3_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _vp]),
+    "ghf_split_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp]),
+    "ghf_split_rows_bytes": (_sz, [_i64, _i32, _i32]),
+    "ghf_weights_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
 }
 
@@ -169,9 +173,8 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
     ls = _req(log_scales, torch.float32, "log_scales")
     hidden_ws = torch.empty(3 * 2 * R * max(Hh, T, 1), dtype=torch.float32, device=dev)
     if out is None:
-        if layout in (WLAYOUT_FRAG16, WLAYOUT_SPLIT3):
-            words = (2 if layout == WLAYOUT_FRAG16 else 3) * R * d_in * d_out
-            W_msg = torch.empty(words, dtype=torch.float32, device=dev)
+        if layout != WLAYOUT_NATURAL:                # one opaque buffer holds [W_msg; W_self] in the kernel's order
+            W_msg = torch.empty(lib.ghf_weights_bytes(R, d_in, d_out, layout) // 4, dtype=torch.float32, device=dev)
             W_self = None
         else:
             W_msg = torch.empty(R, d_in, d_out, dtype=torch.float32, device=dev)
@@ -199,14 +202,20 @@ def input_proj_fwd(x: torch.Tensor, W_in: torch.Tensor, b_in: torch.Tensor, out:
     return h0
 
 
-def split3_rows(h: torch.Tensor, out: Optional[torch.Tensor] = None, row0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
-    """Rows of h cut exactly into three bf16 pieces: [N, 3, d] (bf16 bit patterns in an int16 tensor)."""
+def split_rows(h: torch.Tensor, wlayout: int, out: Optional[torch.Tensor] = None, row0: int = 0,
+               rows: Optional[int] = None) -> torch.Tensor:
+    """Rows of h in the form the message kernel of `wlayout` gathers (include/ghf.h: ghf_split_rows): an opaque int16
+    tensor — SPLIT3: [N, 3, d] bf16 bit patterns; SPLIT2H: N*2*d fp16 bit patterns followed by N float scales."""
+    lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
     if out is None:
-        out = torch.empty(N, 3, d, dtype=torch.int16, device=h.device)
+        nbytes = lib.ghf_split_rows_bytes(N, d, wlayout)
+        if nbytes == 0:
+            raise ValueError(f"weight layout {wlayout} gathers h itself")
+        out = torch.empty((N, 3, d) if wlayout == WLAYOUT_SPLIT3 else (nbytes // 2,), dtype=torch.int16, device=h.device)
     rows = N - row0 if rows is None else rows
-    _check(load().ghf_split3_rows(_ptr(h), N, d, row0, rows, _ptr(out), _stream()), "ghf_split3_rows")
+    _check(lib.ghf_split_rows(_ptr(h), N, d, row0, rows, wlayout, _ptr(out), _stream()), "ghf_split_rows")
     return out
 
 
@@ -216,16 +225,16 @@ def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Option
                       row0: int = 0, rows: Optional[int] = None, flags: int = 0,
                       h_split: Optional[torch.Tensor] = None, h_split_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`plan` is a plan.GraphPlan: the device arrays, the host copy of the item offsets and the split-block scratch.
-    SPLIT3 plans gather from `h_split` (split3_rows(h); made here when the caller has none) and can emit the split
-    form of the rows they write into `h_split_out` for the next layer."""
+    SPLIT3 / SPLIT2H plans gather from `h_split` (split_rows(h, wlayout); made here when the caller has none) and can
+    emit the split form of the rows they write into `h_split_out` for the next layer."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
     if rows is None:
         rows = N - row0
     item0, n_items, partial = plan.items_for(row0, rows, d)
-    if wlayout == WLAYOUT_SPLIT3 and h_split is None:
-        h_split = split3_rows(h)
+    if wlayout in SPLIT_LAYOUTS and h_split is None:
+        h_split = split_rows(h, wlayout)
     _check(lib.ghf_message_layer_fwd(_ptr(h), _ptr(h_split), N, d, _ptr(plan.sorted_key), _ptr(plan.sorted_src), _ptr(plan.seg_off),
                                      _ptr(plan.indeg), _ptr(plan.chunk_tab), _ptr(plan.blk_chunk_off), _ptr(plan.item_tab),
                                      _ptr(plan.blk_item_off), item0, n_items, _ptr(partial), plan.E, plan.R,

@@ -32,10 +32,16 @@ const char* ghf_last_error(void) { return err_buf(); }
 int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks) {
     if (!block_nodes || !wlayout || !chunk_rows || !split_chunks) return set_err(GHF_EINVAL, "message_config: null output pointer");
     int bn = 1, cr = 0, sc = 0;
-    // GHF_KERNEL selects the contraction for A/B runs: "sx" (default) = split-bf16 on the bf16 matrix pipe where a
-    // kernel exists, "pp" / "lockstep" = v_mfma_f32_16x16x4_f32 (message_pp.hip / message_mfma.hip)
+    // GHF_KERNEL selects the contraction for A/B runs: "hx" (default) = two fp16 pieces, three products
+    // (message_hx.hip), "sx" = three bf16 pieces, six products (message_sx.hip), "pp" / "lockstep" =
+    // v_mfma_f32_16x16x4_f32 (message_pp.hip / message_mfma.hip)
     const char* kv = getenv("GHF_KERNEL");
-    if ((!kv || !strcmp(kv, "sx")) && message_sx_config(d, &bn, &cr, &sc)) {
+    if ((!kv || !strcmp(kv, "hx")) && message_hx_config(d, &bn, &cr, &sc)) {
+        *block_nodes = bn;
+        *wlayout = GHF_WLAYOUT_SPLIT2H;
+        *chunk_rows = cr;
+        *split_chunks = sc;
+    } else if (kv && !strcmp(kv, "sx") && message_sx_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_SPLIT3;
         *chunk_rows = cr;
@@ -94,10 +100,28 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in, int
     return launch_input_proj(x, W_in, b_in, N, F, d, h0, (hipStream_t)stream);
 }
 
-int ghf_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, void* stream) {
-    GHF_REQUIRE(h && h_split, "split3_rows: null pointer argument");
-    GHF_REQUIRE(N > 0 && d > 0 && d % 4 == 0 && row0 >= 0 && rows >= 0 && row0 + rows <= N, "split3_rows: bad shape or row range");
-    return launch_split3_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
+size_t ghf_split_rows_bytes(int64_t N, int d, int wlayout) {
+    if (wlayout == GHF_WLAYOUT_SPLIT3) return (size_t)N * d * 6;
+    if (wlayout == GHF_WLAYOUT_SPLIT2H) return (size_t)N * d * 4 + (size_t)N * 4;
+    return 0;
+}
+
+size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout) {
+    const size_t n = (size_t)R * d_in * d_out;
+    switch (wlayout) {
+        case GHF_WLAYOUT_FRAG16:  return 2 * n * 4;
+        case GHF_WLAYOUT_SPLIT3:  return 2 * n * 6;
+        case GHF_WLAYOUT_SPLIT2H: return 2 * n * 4 + (size_t)R * 4;
+        default:                  return n * 4;
+    }
+}
+
+int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, int wlayout, void* h_split, void* stream) {
+    GHF_REQUIRE(h && h_split, "split_rows: null pointer argument");
+    GHF_REQUIRE(N > 0 && d > 0 && d % 4 == 0 && row0 >= 0 && rows >= 0 && row0 + rows <= N, "split_rows: bad shape or row range");
+    if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_split3_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
+    if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_split2h_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
+    return set_err(GHF_EINVAL, "split_rows: layout %d gathers h itself", wlayout);
 }
 
 int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d, const uint32_t* sorted_key, const int32_t* sorted_src,
@@ -117,14 +141,16 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     GHF_REQUIRE(row0 % block_nodes == 0, "message_layer_fwd: row0 must be a multiple of block_nodes");
     GHF_REQUIRE(block_nodes == 1 || (chunk_tab && blk_chunk_off && item_tab && blk_item_off && item0 >= 0 && n_items >= 0),
                 "message_layer_fwd: block plans need the chunk and item tables");
-    GHF_REQUIRE(wlayout != GHF_WLAYOUT_SPLIT3 || h_split, "message_layer_fwd: SPLIT3 weights need h_split (ghf_split3_rows)");
-    GHF_REQUIRE(!h_split_out || (wlayout == GHF_WLAYOUT_SPLIT3 && !(flags & GHF_FLAG_NO_TAIL) && h_split_out != h_split),
-                "message_layer_fwd: h_split_out needs SPLIT3 weights and the fused tail, and must not alias h_split");
+    const bool split = wlayout == GHF_WLAYOUT_SPLIT3 || wlayout == GHF_WLAYOUT_SPLIT2H;
+    GHF_REQUIRE(!split || h_split, "message_layer_fwd: SPLIT3 / SPLIT2H weights need h_split (ghf_split_rows)");
+    GHF_REQUIRE(!h_split_out || (split && !(flags & GHF_FLAG_NO_TAIL) && h_split_out != h_split),
+                "message_layer_fwd: h_split_out needs split weights and the fused tail, and must not alias h_split");
     MsgArgs a{h, h_split, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, item0, n_items,
               partial, E, R, block_nodes, W_msg, W_self, bias, wlayout,
               ln_gamma, ln_beta, ln_eps, row0, rows, h_out, h_split_out, flags};
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
+    if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_message_hx(a, (hipStream_t)stream);
     return launch_message_mfma(a, (hipStream_t)stream);
 }
 

@@ -53,6 +53,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// max over the wave of non-negative values (0 is the identity the disabled DPP rows contribute)
+__device__ __forceinline__ float wave_absmax(float v) {
+    v = fmaxf(v, dpp_take<0xB1, 0xF>(v));
+    v = fmaxf(v, dpp_take<0x4E, 0xF>(v));
+    v = fmaxf(v, dpp_take<0x141, 0xF>(v));
+    v = fmaxf(v, dpp_take<0x140, 0xF>(v));
+    v = fmaxf(v, dpp_take<0x142, 0xA>(v));
+    v = fmaxf(v, dpp_take<0x143, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// GHF_WLAYOUT_SPLIT2H pieces.  s = split2h_shift(largest magnitude of the row / matrix) lifts it into [2^13, 2^14);
+// x 2^s = hi + lo + eps with hi = fp16(x 2^s), lo = fp16(x 2^s - hi), |eps| <= 2^-22 |x 2^s|.  |s| <= 100 keeps 2^s and
+// 2^-s normal fp32 numbers (rows below 2^-87 or above 2^113 lose precision; nothing sane is there).
+__device__ __forceinline__ int split2h_shift(float maxabs) {
+    const int e = ((__float_as_int(maxabs) >> 23) & 255) - 127;
+    const int s = 13 - e;
+    return s < -100 ? -100 : (s > 100 ? 100 : s);
+}
+__device__ __forceinline__ float pow2f(int s) { return __int_as_float((s + 127) << 23); }   // |s| <= 126
+__device__ __forceinline__ void split2h(float xs, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)xs;
+    lo = (_Float16)(xs - (float)hi);
+}
+
 // Sum over a block of NWAVES*64 threads; `red` is >= NWAVES floats of LDS.
 // All threads get the result.  Contains two barriers.
 template <int NWAVES>
@@ -108,6 +133,9 @@ struct MsgArgs {
     int64_t row0; int64_t rows; float* h_out; void* h_split_out; int flags;
 };
 int launch_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
+int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
+int launch_message_hx(const MsgArgs& a, hipStream_t stream);       // fp16 two-piece contraction (d = 128), SPLIT2H weights
+bool message_hx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 int launch_message_generic(const MsgArgs& a, hipStream_t stream);
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
 int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
     const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off,
     const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
     const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int64_t row_end,
-    float* __restrict__ h_out, uint16_t* __restrict__ h_split_out, int no_tail) {
+    float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail) {
     const int64_t blk = blk0 + blockIdx.x;
     const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
     if (i1 - i0 <= 1) return;
@@ -173,14 +173,37 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
 #pragma unroll
         for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
             const int o = lane + 64 * c;
-            if (o < d) {
-                h_out[(size_t)node * d + o] = x[c];
-                if (h_split_out) {
+            if (o < d) h_out[(size_t)node * d + o] = x[c];
+        }
+        if (h_split_out && split_layout == GHF_WLAYOUT_SPLIT3) {
+#pragma unroll
+            for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
+                const int o = lane + 64 * c;
+                if (o < d) {
                     uint16_t pc[3];
                     split3_pieces(x[c], pc);
-                    for (int pl = 0; pl < 3; ++pl) h_split_out[((size_t)node * 3 + pl) * d + o] = pc[pl];
+                    for (int pl = 0; pl < 3; ++pl) ((uint16_t*)h_split_out)[((size_t)node * 3 + pl) * d + o] = pc[pl];
                 }
             }
+        } else if (h_split_out) {                          // SPLIT2H: the wave holds the whole row
+            float mx = 0.f;
+#pragma unroll
+            for (int c = 0; c < COMB_MAX_PER_LANE; ++c)
+                if (lane + 64 * c < d) mx = fmaxf(mx, fabsf(x[c]));
+            const int sh = split2h_shift(wave_absmax(mx));
+            const float up = pow2f(sh);
+            _Float16* sp = (_Float16*)h_split_out + (size_t)node * 2 * d;
+#pragma unroll
+            for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
+                const int o = lane + 64 * c;
+                if (o < d) {
+                    _Float16 hi, lo;
+                    split2h(x[c] * up, hi, lo);
+                    sp[o] = hi;
+                    sp[d + o] = lo;
+                }
+            }
+            if (lane == 0) *(float*)((char*)h_split_out + (size_t)N * d * 4 + (size_t)node * 4) = pow2f(-sh);
         }
     }
 }
@@ -189,7 +212,7 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const int64_t blk0 = a.row0 / a.block_nodes, row_end = a.row0 + a.rows;
     const unsigned grid = (unsigned)cdiv(a.rows, a.block_nodes);
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
-                                                   a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, (uint16_t*)a.h_split_out,
+                                                   a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, a.h_split_out, a.wlayout,
                                                    (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
     GHF_LAUNCH_CHECK();
     return GHF_OK;

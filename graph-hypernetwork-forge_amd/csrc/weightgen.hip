@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restr
                                                             const float* __restrict__ W3, const float* __restrict__ b3,
                                                             const float* __restrict__ log_scale,
                                                             int R, int Hl, int n_out, int head, int d_in, int d_out,
-                                                            int layout, float* __restrict__ out) {
+                                                            int layout, size_t rstride, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_out) return;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restr
         if (lane == 0) {
             const float v = (s + bn) * scale;
             if (head == 2 || layout == GHF_WLAYOUT_NATURAL) {
-                out[(size_t)r * n_out + n] = v;
+                out[(size_t)r * rstride + n] = v;
             } else if (layout == GHF_WLAYOUT_SPLIT3) {
                 const int i = n / d_out, o = n - i * d_out;
                 uint16_t pc[3];
@@ -119,7 +119,7 @@ template <int LAYOUT>
 __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restrict__ z /* [R,Hl] */,
                                                           const float* __restrict__ W3, const float* __restrict__ b3,
                                                           const float* __restrict__ log_scale,
-                                                          int R, int Hl, int n_out, int head, int d,
+                                                          int R, int Hl, int n_out, int head, int d, size_t rstride,
                                                           float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -185,9 +185,48 @@ __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restric
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int n = 16 * mt + 4 * q + s;
-                if (n < n_out) out[(size_t)rc * n_out + n] = (acc[s] + b3[n]) * scale;
+                if (n < n_out) out[(size_t)rc * rstride + n] = (acc[s] + b3[n]) * scale;
             }
         }
+    }
+}
+
+// GHF_WLAYOUT_SPLIT2H, second step.  W holds [R][2d][d] fp32 ([W_msg[r]; W_self[r]] row-major); one workgroup per
+// relation pulls its matrix into LDS, finds the largest magnitude, and rewrites the same bytes as fp16 B fragments
+//   Wh[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8],  piece 0 = fp16(w 2^s), piece 1 = fp16(w 2^s - piece 0)
+// (4 bytes per weight either way: in place); scales[r] = 2^-s.
+__global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, float* __restrict__ scales, int d) {
+    extern __shared__ float wbuf[];                      // [2d][d]
+    __shared__ float red[16];
+    const int r = blockIdx.x, tid = threadIdx.x, n = 2 * d * d;
+    float* __restrict__ mine = W + (size_t)r * n;
+    float mx = 0.f;
+    for (int i = tid; i < n / 4; i += 1024) {
+        const float4 v = ((const float4*)mine)[i];
+        ((float4*)wbuf)[i] = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = wave_absmax(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();                                     // also: every load of `mine` happened before any store below
+    mx = 0.f;
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    const int sh = split2h_shift(mx);
+    const float up = pow2f(sh);
+    if (tid == 0) scales[r] = pow2f(-sh);
+    const int NKS = d >> 4;                              // k-steps of 32 over kk in [0, 2d)
+    _Float16* __restrict__ dst = (_Float16*)mine;
+    // one 16-byte granule (8 consecutive kk of one column) of one piece per thread and step
+    for (int g = tid; g < n / 8; g += 1024) {
+        const int slot = g & 63, fk = g >> 6;            // lane slot within the fragment; fragment = (ct, ks)
+        const int ks = fk % NKS, ct = fk / NKS;
+        const int o = ct * 16 + (slot & 15), kk0 = ks * 32 + (slot >> 4) * 8;
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split2h(wbuf[(kk0 + e) * d + o] * up, hi[e], lo[e]);
+        _Float16* p = dst + ((size_t)fk * 2 * 64 + slot) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { p[e] = hi[e]; p[512 + e] = lo[e]; }
     }
 }
 
@@ -198,15 +237,18 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
     GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
     GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
     GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
-    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT3,
-                "weightgen: bad layout %d", layout);
+    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT3 ||
+                    layout == GHF_WLAYOUT_SPLIT2H, "weightgen: bad layout %d", layout);
+    if (layout == GHF_WLAYOUT_SPLIT2H)
+        GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && (size_t)2 * d_in * d_out * 4 <= 128 * 1024 && W_self == nullptr,
+                    "weightgen: SPLIT2H needs d_in == d_out, d %% 32 == 0, d <= 128 and W_self == NULL");
     if (layout == GHF_WLAYOUT_FRAG16)
         GHF_REQUIRE(d_in == d_out && (d_in % 16) == 0 && W_self == nullptr,
                     "weightgen: FRAG16 needs d_in == d_out, d %% 16 == 0 and W_self == NULL");
     else if (layout == GHF_WLAYOUT_SPLIT3)
         GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && W_self == nullptr,
                     "weightgen: SPLIT3 needs d_in == d_out, d %% 32 == 0 and W_self == NULL");
-    else
+    else if (layout == GHF_WLAYOUT_NATURAL)
         GHF_REQUIRE(W_self != nullptr, "weightgen: NATURAL layout needs W_self");
 
     HeadPtrs P;
@@ -227,25 +269,37 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
         const float* W3 = P.w[head][num_hidden];
         const float* b3 = P.b[head][num_hidden];
         const int n_out = head == 2 ? d_out : n_mat;
-        float* out = head == 2 ? bias : (layout != GHF_WLAYOUT_NATURAL ? W_msg : (head == 0 ? W_msg : W_self));
+        // SPLIT2H: the two matrix heads first write [R][2d][d] fp32 into W_msg (natural order, W_self below W_msg),
+        // which wg_pack2h_kernel then rewrites in place
+        const bool nat = layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_SPLIT2H;
+        const size_t rstride = (layout == GHF_WLAYOUT_SPLIT2H && head != 2) ? (size_t)2 * n_mat : (size_t)n_out;
+        float* out = head == 2 ? bias : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg + (size_t)head * n_mat
+                                         : (layout != GHF_WLAYOUT_NATURAL ? W_msg : (head == 0 ? W_msg : W_self)));
+        const int klayout = nat ? GHF_WLAYOUT_NATURAL : layout;
         const bool mfma_ok = head != 2 && (Hl % 16) == 0 &&
                              ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
         if (mfma_ok && layout == GHF_WLAYOUT_SPLIT3) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_SPLIT3><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);
+                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, rstride, out);
         } else if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);
+                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, rstride, out);
         } else if (mfma_ok) {
             const int mtiles = (n_mat + 15) / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_NATURAL><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, out);
+                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, rstride, out);
         } else {
             wg_out_simple_kernel<<<(n_out + 3) / 4, 256, 0, stream>>>(z, W3, b3, log_scales + head, R, Hl, n_out,
-                                                                      head, d_in, d_out, layout, out);
+                                                                      head, d_in, d_out, klayout, rstride, out);
         }
+        GHF_LAUNCH_CHECK();
+    }
+    if (layout == GHF_WLAYOUT_SPLIT2H) {
+        const size_t lds = (size_t)2 * n_mat * 4;
+        GHF_HIP_CHECK(hipFuncSetAttribute((const void*)wg_pack2h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out);
         GHF_LAUNCH_CHECK();
     }
     return GHF_OK;

@@ -86,8 +86,8 @@ class NativeOps:
         return model.weight_generators[l].generate(text_embs, plan.wlayout)
 
     def split_rows(self, plan, h):
-        """What the message kernel gathers: h itself, or its rows cut into bf16 pieces (SPLIT3 kernels)."""
-        return _native.split3_rows(h) if plan.wlayout == _native.WLAYOUT_SPLIT3 else None
+        """What the message kernel gathers: h itself, or its rows cut into 16-bit pieces."""
+        return _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
 
     def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int) -> None:
         norm = model.layer_norms[l]

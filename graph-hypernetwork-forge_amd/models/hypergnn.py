@@ -127,9 +127,9 @@ class HyperGNN(nn.Module):
         h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach())
         h_next = torch.empty_like(h)
         lo, hi = plan.row_lo, (plan.row_hi or plan.N)
-        # SPLIT3 kernels gather rows already cut into bf16 pieces; a layer's tail emits them for the next layer
-        split = plan.wlayout == _native.WLAYOUT_SPLIT3
-        hs = _native.split3_rows(h) if split else None
+        # the 16-bit-piece kernels gather rows already cut into pieces; a layer's tail emits them for the next layer
+        split = plan.wlayout in _native.SPLIT_LAYOUTS
+        hs = _native.split_rows(h, plan.wlayout) if split else None
         hs_next = torch.empty_like(hs) if split else None
         last = len(self.weight_generators) - 1
         for l, (gen, norm) in enumerate(zip(self.weight_generators, self.layer_norms)):
@@ -141,7 +141,7 @@ class HyperGNN(nn.Module):
             if exchange is not None:
                 exchange(h_next)
                 if split and l < last:
-                    _native.split3_rows(h_next, out=hs_next)
+                    _native.split_rows(h_next, plan.wlayout, out=hs_next)
             h, h_next = h_next, h
             hs, hs_next = hs_next, hs
         return h

@@ -44,6 +44,9 @@ extern "C" {
 #define GHF_WLAYOUT_FRAG16  1 /* MFMA 16x16x4 B-fragment order: Wfrag[R][d/16][2d/16][64 lanes][4] */
 #define GHF_WLAYOUT_SPLIT3  2 /* bf16 MFMA 16x16x32 B-fragment order, every fp32 weight cut exactly into 3 bf16 pieces:
                                  Wsplit[R][d/16][2d/32][3 pieces][64 lanes][8] bf16 = 6 bytes per weight */
+#define GHF_WLAYOUT_SPLIT2H 3 /* fp16 MFMA 16x16x32 B-fragment order, every weight of relation r scaled by a power of two
+                                 2^s(r) and cut into 2 fp16 pieces: Wh[R][d/16][2d/32][2 pieces][64 lanes][8] fp16 = 4 bytes
+                                 per weight, followed by float 2^-s(r) [R] */
 
 int         ghf_abi_version(void);
 const char* ghf_last_error(void);
@@ -118,10 +121,10 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
  * item0 / n_items: the work items of the blocks of the row range, i.e. blk_item_off[row0/BN] and
  * blk_item_off[ceil((row0+rows)/BN)] - item0 (host copies of two plan words); partial: scratch of
  * status[2]*BN*d floats for the split blocks (may be NULL when status[2] == 0).
- * h_split: the rows of h cut into bf16 pieces by ghf_split3_rows (or by a previous call's h_split_out); required
- * when wlayout == GHF_WLAYOUT_SPLIT3, ignored otherwise.  h_split_out (optional, SPLIT3 only, not with
+ * h_split: the rows of h cut into pieces by ghf_split_rows (or by a previous call's h_split_out); required when
+ * wlayout is SPLIT3 or SPLIT2H, ignored otherwise.  h_split_out (optional, those layouts only, not with
  * GHF_FLAG_NO_TAIL): receives the split form of the h_out rows written by this call, for the next layer. */
-int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* [N][3][d] bf16 or NULL */, int64_t N, int d,
+int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* ghf_split_rows output or NULL */, int64_t N, int d,
                           const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg,
                           const int32_t* chunk_tab, const int32_t* blk_chunk_off,
@@ -131,12 +134,19 @@ int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* [N]
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps,
                           int64_t row0, int64_t rows, float* h_out /* [N,d] */,
-                          void* h_split_out /* [N][3][d] bf16 or NULL */, int flags, void* stream);
+                          void* h_split_out /* or NULL */, int flags, void* stream);
 
-/* Rows [row0, row0+rows) of h [N,d] cut exactly into three bf16 pieces each (x = p0 + p1 + p2: 8 + 8 + 8 significand
- * bits, by truncation): h_split[v][piece][k] bf16, 6*d bytes per row.  This is what the SPLIT3 message kernel gathers
- * (the split is done once per row here instead of once per edge there).  d % 4 == 0. */
-int ghf_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, void* stream);
+/* Rows [row0, row0+rows) of h [N,d] in the form the message kernel of `wlayout` gathers (the split is done once per
+ * row here instead of once per edge there); h_split holds ghf_split_rows_bytes(N, d, wlayout) bytes:
+ *   SPLIT3 : h_split[v][3 pieces][d] bf16 — x = p0 + p1 + p2 exactly (8 + 8 + 8 significand bits, by truncation);
+ *   SPLIT2H: h_split[v][2 pieces][d] fp16 — x 2^s(v) = hi + lo (22 significand bits), 2^s(v) lifting the row's largest
+ *            magnitude into [2^13, 2^14) — followed by float 2^-s(v) [N].
+ * Other layouts gather h itself (ghf_split_rows_bytes == 0).  d % 4 == 0. */
+size_t ghf_split_rows_bytes(int64_t N, int d, int wlayout);
+int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, int wlayout, void* h_split, void* stream);
+
+/* Bytes of the W_msg buffer ghf_weightgen_fwd fills in `wlayout` (NATURAL: one of the two [R,d_in,d_out] matrices). */
+size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout);
 
 /* ---- K3 alone -------------------------------------------------------------------------
  * Replaces models/hypergnn.py:288-296 on rows [row0,row0+rows): agg already holds

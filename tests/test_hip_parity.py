@@ -38,12 +38,14 @@ def test_native_library_is_loaded():
     lib = _native.load()
     assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
-    assert _native.message_config(128) == (162, _native.WLAYOUT_SPLIT3, 48, 128)
+    assert _native.message_config(128) == (216, _native.WLAYOUT_SPLIT2H, 48, 128)
     assert _native.message_config(64) == (216, _native.WLAYOUT_FRAG16, 48, 128)
     assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
-    os.environ["GHF_KERNEL"] = "pp"
     try:
+        os.environ["GHF_KERNEL"] = "pp"
         assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48, 128)
+        os.environ["GHF_KERNEL"] = "sx"
+        assert _native.message_config(128) == (162, _native.WLAYOUT_SPLIT3, 48, 128)
     finally:
         del os.environ["GHF_KERNEL"]
 
@@ -143,6 +145,56 @@ def _to_split3(Wm, Ws):
     return np.ascontiguousarray(pc.transpose(1, 5, 2, 0, 3, 6, 4)).reshape(-1).view(np.float32)   # r, ct, ks, piece, q, c16, e
 
 
+def _split2h_np(x, axis_groups):
+    """SPLIT2H pieces of x: per group (all axes but the first `axis_groups`) s = 13 - floor(log2(max |x|)) clamped to
+    +-100; hi = fp16(x 2^s), lo = fp16(x 2^s - hi).  Returns (hi, lo as float16, 2^-s as float32 per group)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    mx = np.abs(x).reshape(x.shape[:axis_groups] + (-1,)).max(axis=-1)
+    e = ((mx.view(np.uint32) >> 23) & 255).astype(np.int32) - 127                        # exponent field, as the device
+    sh = np.clip(13 - e, -100, 100)
+    up = np.ldexp(np.float32(1), sh).astype(np.float32).reshape(sh.shape + (1,) * (x.ndim - axis_groups))
+    xs = x * up
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo, np.ldexp(np.float32(1), -sh).astype(np.float32)
+
+
+def _to_split2h(Wm, Ws):
+    """Wh[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8] fp16 + float 2^-s [R], as an opaque float32 buffer."""
+    R, d, _ = Wm.shape
+    hi, lo, down = _split2h_np(np.concatenate([Wm, Ws], axis=1), 1)                       # [R, 2d, d]
+    pc = np.stack([hi, lo]).reshape(2, R, 2 * d // 32, 4, 8, d // 16, 16)                 # piece, r, ks, q, e, ct, c16
+    frag = np.ascontiguousarray(pc.transpose(1, 5, 2, 0, 3, 6, 4)).reshape(-1)            # r, ct, ks, piece, q, c16, e
+    return np.concatenate([frag.view(np.float32), down])
+
+
+def _rows_split2h(h):
+    """What ghf_split_rows(SPLIT2H) writes: [N][2][d] fp16 then float 2^-s [N], as int16."""
+    hi, lo, down = _split2h_np(h, 1)
+    return np.concatenate([np.stack([hi, lo], axis=1).reshape(-1).view(np.int16), down.view(np.int16)])
+
+
+def test_split2h_layout_is_the_two_piece_cut_of_natural():
+    c = [x for x in cases.WG_CASES if x.name == "wg_c3_shape"][0]
+    gen = WeightGenerator(c.text_dim, c.d_in, c.d_out, hidden_dim=c.hidden_dim)
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in c.params().items()})
+    gen = gen.to(DEV).eval()
+    x = torch.from_numpy(c.text_emb()).to(DEV)
+    with torch.no_grad():
+        Wm, Ws, b = gen.generate(x, _native.WLAYOUT_NATURAL)
+        Wh, none, b2 = gen.generate(x, _native.WLAYOUT_SPLIT2H)
+    assert none is None and torch.equal(b, b2)
+    Wm, Ws = Wm.cpu().numpy(), Ws.cpu().numpy()
+    assert np.array_equal(Wh.cpu().numpy().view(np.uint16), _to_split2h(Wm, Ws).view(np.uint16))
+    # the pieces carry 22 significand bits of every weight within 2^-16 of its matrix' largest
+    cat = np.concatenate([Wm, Ws], axis=1)
+    hi, lo, down = _split2h_np(cat, 1)
+    back = (hi.astype(np.float64) + lo.astype(np.float64)) * down.astype(np.float64)[:, None, None]
+    big = np.abs(cat) >= np.abs(cat).max(axis=(1, 2), keepdims=True) * 2.0 ** -10
+    assert np.all(np.abs(back - cat)[big] <= np.abs(cat[big]) * 2.0 ** -21)
+    assert np.all(np.abs(back - cat) <= np.abs(cat).max(axis=(1, 2), keepdims=True) * 2.0 ** -36 + np.abs(cat) * 2.0 ** -21)
+
+
 def test_split3_layout_is_an_exact_three_piece_cut_of_natural():
     c = [x for x in cases.WG_CASES if x.name == "wg_c3_shape"][0]
     gen = WeightGenerator(c.text_dim, c.d_in, c.d_out, hidden_dim=c.hidden_dim)
@@ -159,30 +211,39 @@ def test_split3_layout_is_an_exact_three_piece_cut_of_natural():
     assert np.array_equal((_bf16_np(p[0]) + _bf16_np(p[1])) + _bf16_np(p[2]), np.concatenate([Wm, Ws], axis=1))
 
 
-def test_split3_rows_and_the_fused_tail_agree():
-    """ghf_split3_rows is the exact 3-piece cut, and a layer's h_split_out equals split3_rows of its h_out."""
+def test_split_rows_and_the_fused_tail_agree(kernel):
+    """ghf_split_rows matches its numpy restatement, and a layer's h_split_out equals split_rows of its h_out."""
+    if kernel == "pp":
+        pytest.skip("the fp32 MFMA kernel gathers h itself")
     d, N, E, R = 128, 3000, 30000, 16
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=77, kind="uniform")
+    h[5] = 0.0                                                                            # an all-zero row
+    h[6] *= 1e-30
+    h[7] *= 1e20
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
-    h_d = t(h)
-    hs = _native.split3_rows(h_d)
-    want = np.stack(_split3_np(h), axis=1)                                                # [N, 3, d] uint16
-    assert np.array_equal(hs.cpu().numpy().view(np.uint16), want)
-    part = torch.zeros_like(hs)
-    _native.split3_rows(h_d, out=part, row0=100, rows=50)
-    assert torch.equal(part[100:150], hs[100:150]) and not part[:100].any() and not part[150:].any()
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
-    assert plan.wlayout == _native.WLAYOUT_SPLIT3
+    wl = plan.wlayout
+    assert wl == {"hx": _native.WLAYOUT_SPLIT2H, "sx": _native.WLAYOUT_SPLIT3}[kernel]
+    h_d = t(h)
+    hs = _native.split_rows(h_d, wl)
+    want = np.stack(_split3_np(h), axis=1).view(np.int16) if kernel == "sx" else _rows_split2h(h)
+    assert np.array_equal(hs.cpu().numpy().reshape(-1), want.reshape(-1))
+    part = torch.zeros_like(hs)
+    _native.split_rows(h_d, wl, out=part, row0=100, rows=50)
+    per_row = 3 * d if kernel == "sx" else 2 * d
+    a, z = hs.reshape(-1)[: N * per_row].reshape(N, per_row), part.reshape(-1)[: N * per_row].reshape(N, per_row)
+    assert torch.equal(z[100:150], a[100:150]) and not z[:100].any() and not z[150:].any()
     W = _pack_weights(plan, Wm, Ws)[0]
     out, out_split = torch.empty_like(h_d), torch.zeros_like(hs)
-    _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, out, h_split=hs,
-                              h_split_out=out_split)
-    assert torch.equal(out_split, _native.split3_rows(out))
+    _native.message_layer_fwd(h_d, plan, W, None, t(b), wl, t(gamma), t(beta), 1e-5, out, h_split=hs, h_split_out=out_split)
+    assert torch.equal(out_split, _native.split_rows(out, wl))
 
 
 def _pack_weights(plan, Wm, Ws):
     """(W, W_self) device tensors in the layout the plan's kernel reads."""
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    if plan.wlayout == _native.WLAYOUT_SPLIT2H:
+        return t(_to_split2h(Wm, Ws)), None
     if plan.wlayout == _native.WLAYOUT_SPLIT3:
         return t(_to_split3(Wm, Ws)), None
     if plan.wlayout == _native.WLAYOUT_FRAG16:
@@ -190,9 +251,10 @@ def _pack_weights(plan, Wm, Ws):
     return t(Wm), t(Ws)
 
 
-@pytest.fixture(params=["sx", "pp"])
+@pytest.fixture(params=["hx", "sx", "pp"])
 def kernel(request, monkeypatch):
-    """Both contractions of the d = 128 message kernel: split-bf16 (default) and v_mfma_f32_16x16x4_f32."""
+    """The contractions of the d = 128 message kernel: two fp16 pieces (default), three bf16 pieces, and
+    v_mfma_f32_16x16x4_f32."""
     monkeypatch.setenv("GHF_KERNEL", request.param)
     return request.param
 
@@ -307,8 +369,8 @@ def _to_frag16(Wm, Ws):
 ])
 @pytest.mark.parametrize("no_tail", [False, True])
 def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail, kernel):
-    if kernel == "pp" and d != 128:
-        pytest.skip("only d = 128 has two contractions")
+    if kernel != "hx" and d != 128:
+        pytest.skip("only d = 128 has several contractions")
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=1000 + d + R, kind=kind)
     plan = build_plan(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), [""] * R, N, d, DEV)
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
@@ -332,8 +394,8 @@ def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail, kernel):
 def test_split_hub_blocks_match_oracle(d, kernel):
     """Power-law in-degrees: blocks with more chunks than split_chunks are cut into work items whose partial sums a
     second kernel combines in item order (ghf.h: item_tab) — same result, still bitwise reproducible."""
-    if kernel == "pp" and d != 128:
-        pytest.skip("only d = 128 has two contractions")
+    if kernel != "hx" and d != 128:
+        pytest.skip("only d = 128 has several contractions")
     N, E, R = 6000, 150000, 8
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=4242, kind="powerlaw")
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731

@@ -14,16 +14,17 @@ for kind in ("uniform", "powerlaw"):
     plan = build_plan(torch.from_numpy(ei).to(dev), torch.from_numpy(rel).to(dev), [""] * R, N, d, dev)
     boff = plan.blk_chunk_off.cpu().numpy()
     per_blk = np.diff(boff)
-    h = torch.randn(N, d, device=dev); W = torch.randn((3 if plan.wlayout == _native.WLAYOUT_SPLIT3 else 2) * R * d * d, device=dev) * 0.05
-    if plan.wlayout == _native.WLAYOUT_SPLIT3:
+    h = torch.randn(N, d, device=dev); W = torch.randn(_native.load().ghf_weights_bytes(R, d, d, plan.wlayout) // 4, device=dev) * 0.05
+    if plan.wlayout in _native.SPLIT_LAYOUTS:
         W = (W.view(torch.int32) & 0x3FFF3FFF).view(torch.float32)
     b = torch.randn(R, d, device=dev); g = torch.ones(d, device=dev); bt = torch.zeros(d, device=dev)
     out = torch.empty_like(h)
+    hs = _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
     for _ in range(2):
-        _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out)
+        _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out, h_split=hs)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5):
-        _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out)
+        _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out, h_split=hs)
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
     print(f"{kind:9s}: max in-degree {deg.max():8d}; chunks per block mean {per_blk.mean():7.1f} max {per_blk.max():7d}; "
           f"items {int(plan.item_off_host[-1])} (blocks {len(per_blk)}), scratch slots {plan.n_slots}; message layer {ms:8.2f} ms")

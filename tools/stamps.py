@@ -25,20 +25,22 @@ dev = torch.device("cuda:0")
 ei, rel = synth.make_graph_arrays(N, E, R, 1003)
 plan = build_plan(torch.from_numpy(ei).to(dev), torch.from_numpy(rel).to(dev), [""] * R, N, d, dev)
 h = torch.randn(N, d, device=dev)
-W = torch.randn((3 if plan.wlayout == _native.WLAYOUT_SPLIT3 else 2) * R * d * d, device=dev) * 0.05
-if plan.wlayout == _native.WLAYOUT_SPLIT3:          # any finite bf16 bit patterns will do for timing
+W = torch.randn(_native.load().ghf_weights_bytes(R, d, d, plan.wlayout) // 4, device=dev) * 0.05
+if plan.wlayout in _native.SPLIT_LAYOUTS:          # any finite bf16 bit patterns will do for timing
     W = (W.view(torch.int32) & 0x3FFF3FFF).view(torch.float32)
 b = torch.randn(R, d, device=dev)
 g, bt = torch.ones(d, device=dev), torch.zeros(d, device=dev)
 out = torch.empty_like(h)
+hs = _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
 for _ in range(2):
-    _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out)
+    _native.message_layer_fwd(h, plan, W, None, b, plan.wlayout, g, bt, 1e-5, out, h_split=hs)
 torch.cuda.synchronize()
 nb = min(8192, -(-N // plan.block_nodes))
 buf = np.zeros(8192 * 8 * 8, dtype=np.uint64)
 lockstep = os.environ.get("GHF_KERNEL") == "lockstep" or d != 128
-fn = lib.ghf_debug_read_stamps if lockstep else (lib.ghf_debug_read_stamps_sx if plan.wlayout == _native.WLAYOUT_SPLIT3
-                                                 else lib.ghf_debug_read_stamps_pp)
+fn = lib.ghf_debug_read_stamps if lockstep else {_native.WLAYOUT_SPLIT3: "ghf_debug_read_stamps_sx", _native.WLAYOUT_SPLIT2H: "ghf_debug_read_stamps_hx"}.get(plan.wlayout, "ghf_debug_read_stamps_pp")
+if isinstance(fn, str):
+    fn = getattr(lib, fn)
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.size) == 0
@@ -46,11 +48,11 @@ st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
 nw = d // 16
 st = st[:, :nw]
 tot = st.sum(axis=2)
-sx = plan.wlayout == _native.WLAYOUT_SPLIT3
+sx = plan.wlayout in _native.SPLIT_LAYOUTS
 if lockstep:
     names = ["mem wait", "barrier", "prefetch issue", "compute", "scatter", "bookkeeping", "tail", "-"]
 elif sx:   # producer / consumer kernel (message_sx.hip): waves 0-3 consume, 4-7 produce
-    names = ["barrier wait", "consumer: mfma stage", "producer: gather issue", "producer: split+commit", "consumer: bias+scatter", "-", "drain+tail", "-"]
+    names = ["barrier wait", "consumer: unscale+rest", "producer: gather issue", "producer: commit", "consumer: bias+scatter", "consumer: k-step 0 (issue-stamped)", "drain+tail", "consumer: k-steps 1-3 (issue-stamped)"]
 else:   # ping-pong kernel (message_pp.hip)
     names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: gather issue"]
 print(f"blocks={nb} waves/block={nw} mean cycles per wave = {tot.mean():.0f}")
