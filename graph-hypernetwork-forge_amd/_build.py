@@ -25,6 +25,10 @@ if VARIANT == "stamps":
     FLAGS.append("-DGHF_STAMPS")
 elif VARIANT == "ablate":
     FLAGS.append("-DGHF_ABLATE")
+elif VARIANT.startswith("exp"):
+    # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags
+    # of the "ablate" build they add no branches, so what is left runs exactly as in the product
+    FLAGS.append("-DGHF_EXP=" + VARIANT[3:])
 
 
 def hipcc_path() -> str:

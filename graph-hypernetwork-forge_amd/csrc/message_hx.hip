@@ -68,6 +68,12 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #define HX_STAMP(i)
 #endif
 
+// Compile-time ablations (GHF_VARIANT=exp<mask>, timing only, wrong results): 1 no B refills, 2 no gathers, 4 no main
+// MFMAs, 8 no scatter, 16 gather one hot row, 32 one relation's weights
+#ifndef GHF_EXP
+#define GHF_EXP 0
+#endif
+
 template <int D> struct HxCfg;
 template <> struct HxCfg<128> { static constexpr int BN = 216, MTC = 3; };   // 159 KB LDS: 1 workgroup/CU
 
@@ -143,9 +149,13 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
         const int c = c_begin + (k < nchunks ? k : 0) + vzero;          // past the end: a valid (ignored) entry
         return *hx_at<i32x2>(chunk_tab, (uint32_t)c * 8u);
     };
-    auto decode = [&](i32x2 d, int k) -> HxChunk {
+    // Past the end of the sequence this returns the item's first chunk again: the programs below issue the SAME loads in
+    // every iteration (the extra ones, once per item, are never used).  Loads under a uniform branch would make hipcc's
+    // s_waitcnt insertion assume the path without them, i.e. wait for the newest requests where the oldest are meant —
+    // which silently turns every prefetch into a blocking load.
+    auto decode = [&](i32x2 d) -> HxChunk {
         const int w0 = __builtin_amdgcn_readfirstlane(d[0]), w1 = __builtin_amdgcn_readfirstlane(d[1]);
-        return k < nchunks ? HxChunk{w1 >> 8, w0, w1 & 127, (w1 >> 7) & 1} : HxChunk{0, 0, 0, 0};
+        return HxChunk{w1 >> 8, w0, w1 & 127, (w1 >> 7) & 1};
     };
 
     // ---- producers -----------------------------------------------------------------------------------------------
@@ -175,11 +185,13 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
         const uint32_t nbase = ph == 0 ? 0u : (uint32_t)node0 - kbase;
 #pragma unroll
         for (int m = 0; m < MTC; ++m) {
-            if (m >= mts) continue;
             const int v = __shfl(word, m * 16 + tw * RPW + lane / GPR, 64);
             uint32_t node = (ph == 0 ? (uint32_t)(v & SRC_MASK) : (uint32_t)v) + nbase;
-            if (dbg & 1) node = (uint32_t)node0;
-            const int off = (int)(node * (uint32_t)HROW) + ((lane % GPR) << 4);
+            if ((dbg & 1) || (GHF_EXP & 16)) node = (uint32_t)node0;
+            // no branch around the loads of a dead tile (see decode): they get an offset past the end of the buffer,
+            // which the buffer's range check answers with zeros without touching memory
+            const int off = m < mts ? (int)(node * (uint32_t)HROW) + ((lane % GPR) << 4) : 0x7FFFFF00;
+            if (GHF_EXP & 2) continue;
 #pragma unroll
             // source rows are read about once per CU from a 512 MB table: non-temporal, so that they do not push the
             // relations' weights (re-read by every workgroup) out of the 4 MiB L2; destination rows are re-read ~10x
@@ -188,16 +200,13 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
                                             : __builtin_amdgcn_raw_buffer_load_b128(rsH, off + pl * ROWB, 0, 0);
         }
     };
-    auto stage_commit = [&](const i32x4 (&stg)[IPW], char* Abuf, int rows) {
-        const int mts = (rows + 15) >> 4;
+    auto stage_commit = [&](const i32x4 (&stg)[IPW], char* Abuf) {
         const int r16 = tw * RPW + lane / GPR;                             // row within its tile
         char* dst = Abuf + r16 * ROWB + (((lane % GPR) ^ r16) << 4);
 #pragma unroll
-        for (int m = 0; m < MTC; ++m) {
-            if (m >= mts) continue;
+        for (int m = 0; m < MTC; ++m)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) *(i32x4*)(dst + m * 16 * ROWB + pl * PLANE) = stg[m * NPL + pl];
-        }
     };
     // a chunk's words for the consumers: (byte offset of the row's target in the block sums) | run head; per row
     // tile the mask of rows that continue a run of equal destinations; the rows' scales for either phase
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     const uint32_t wsc_off = (uint32_t)((uint64_t)R * 2 * D * D * (NPL * 2));
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wsplit, 0, (int)wsc_off, 0x00020000);
     auto b_soff = [&](int r, int ph, int t) -> int {
-        if (dbg & 2) r = 0;
+        if ((dbg & 2) || (GHF_EXP & 32)) r = 0;
         return __builtin_amdgcn_readfirstlane((((r * NT + tw * NTW + t) * NKS + ph * KS) * NPL) * 1024);
     };
     const int lane16 = lane * 16;
@@ -244,13 +253,81 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     // LDS (read one step ahead), and for each of the wave's column fragments the three piece products, smallest
     // first, into per-stage accumulators; when the phase ends they are scaled by 2^-s(row) 2^-s(relation) — exact —
     // and added to the chunk's rows.  One code path: dead row tiles (m >= mt) skip their MFMAs.
+    // ---- scatter --------------------------------------------------------------------------------------------------
+    // After a chunk's second phase its rows (acc) join the block sums.  All MTC tiles, no branch around memory
+    // operations (see decode): rows of dead tiles have dummy targets.
+    // Segment sum: a tile with a run of equal destinations is multiplied by S[i][k] = (head(k) == i) on the fp32 MFMA;
+    // then a plain LDS read-add-write through inline asm (see message_mfma.hip).  The block sums keep a wave's 32
+    // columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column 32*tw + 16*t + c16; the tail undoes it), so a
+    // lane's two values are adjacent and move with one 64-bit access.
+    // (Interleaving these pieces with the next chunk's MFMAs was tried and measured the same: the stage period is set
+    // by how long the weights take to arrive, not by this wave's instruction count.)
+    const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16 * NTW);
+    auto scatter_chunk = [&](const int* meta, bool in_order) {
+        i32x4 mq[MTC];
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) mq[m] = *(const i32x4*)(meta + m * 16 + 4 * q);
+        const i32x4 runs = *(const i32x4*)(meta + CR);
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) {
+            if (__builtin_amdgcn_readfirstlane(runs[m])) {
+                f32x4 y[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) y[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float sel = ((mq[m][s] & 15) == c16) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, acc[m][t][s], y[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[m][t] = y[t];
+            }
+        }
+        unsigned addr[MTC][4];
+        f32x2 v[MTC][4];
+        auto rd = [&](int m) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                addr[m][s] = strip + ((unsigned)mq[m][s] & ~15u);           // the run's target row, or a dummy
+                asm volatile("ds_read_b64 %0, %1" : "=v"(v[m][s]) : "v"(addr[m][s]) : "memory");
+            }
+        };
+        auto wr = [&](int m) {
+            asm volatile("" : "+v"(v[m][0]), "+v"(v[m][1]), "+v"(v[m][2]), "+v"(v[m][3]));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x2 r = v[m][s] + (f32x2){acc[m][0][s], acc[m][1][s]};
+                asm volatile("ds_write_b64 %0, %1" :: "v"(addr[m][s]), "v"(r) : "memory");
+            }
+        };
+        if (!in_order) {                                // no run continues into the next tile: the tiles touch disjoint rows
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) rd(m);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) wr(m);
+        } else {
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                rd(m);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wr(m);
+            }
+        }
+    };
+
     const int arow = c16 * ROWB;
-    auto compute_stage = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next, bool has_next) {
+    auto compute_stage = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+                             const float (&bias_v)[NTW]) {
         f32x4 part[MTC][NTW];
 #pragma unroll
         for (int m = 0; m < MTC; ++m)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) part[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 sc[MTC];                                     // the rows' scales (rows 4q .. 4q+3 of tile m), needed when the phase ends
+#pragma unroll
+        for (int m = 0; m < MTC; ++m) sc[m] = *(const f32x4*)(meta + CR + 16 + ph * CR + m * 16 + 4 * q);
         i32x4 a[3][NPL];                                   // A fragments of (k-step, tile) positions p, p+1, p+2
         auto lda = [&](int j, int m, i32x4 (&dst)[NPL]) {
             const char* src = Abuf + arow + (((4 * j + q) ^ c16) << 4) + m * 16 * ROWB;
@@ -265,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
             for (int m = 0; m < MTC; ++m) {
                 const int p = j * MTC + m, cur = p % 3;
                 if (p + 2 < KS * MTC) lda((p + 2) / MTC, (p + 2) % MTC, a[(p + 2) % 3]);
-                if (m < mt && !(dbg & 4)) {
+                if (m < mt && !(dbg & 4) && !(GHF_EXP & 4)) {
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
                         auto fma = [&](int pa, int pb) {
@@ -279,64 +356,19 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (has_next && !(dbg & 16)) load_b_step(r_next, ph_next, j);
+            if (!(dbg & 16) && !(GHF_EXP & 1)) load_b_step(r_next, ph_next, j);
             __builtin_amdgcn_sched_barrier(0);
             if (j == 0) HX_STAMP(5); else if (j == KS - 1) HX_STAMP(7);
         }
-        // take the scales out: rows 4q .. 4q+3 of tile m
+        // take the scales out: rows 4q .. 4q+3 of tile m; bias[r], once per edge row, is the addend of phase 0
 #pragma unroll
         for (int m = 0; m < MTC; ++m) {
             if (m >= mt) continue;
-            const f32x4 sc = *(const f32x4*)(meta + CR + 16 + ph * CR + m * 16 + 4 * q);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float f = sc[s] * wscale;
+                const float f = sc[m][s] * wscale;
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[m][t][s] = ph == 0 ? part[m][t][s] * f : fmaf(part[m][t][s], f, acc[m][t][s]);
-            }
-        }
-    };
-
-    // Segment-sum the finished rows by destination into this wave's column strips.  live = row tiles of the chunk;
-    // a tile without a run of equal destinations is its own segment sum and skips the MFMAs.  Then a plain LDS
-    // read-add-write through inline asm (see message_mfma.hip), tile by tile: a run may continue into the next tile.
-    // The block sums keep a wave's 32 columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column
-    // 32*tw + 16*t + c16; the tail undoes it), so a lane's two values are adjacent and move with one 64-bit access.
-    auto scatter_chunk = [&](int live, const int* meta) {
-        const unsigned strip = (unsigned)(size_t)(lptr_t)(acc_lds + tw * 16 * NTW + c16 * NTW);
-        i32x4 mq[MTC];
-#pragma unroll
-        for (int m = 0; m < MTC; ++m) mq[m] = *(const i32x4*)(meta + m * 16 + 4 * q);
-        const i32x4 runs = *(const i32x4*)(meta + CR);
-#pragma unroll
-        for (int m = 0; m < MTC; ++m) {
-            if (m >= live) continue;
-            f32x4 y[NTW];
-            if (__builtin_amdgcn_readfirstlane(runs[m])) {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) y[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float sel = ((mq[m][s] & 15) == c16) ? 1.0f : 0.0f;   // S[i = c16][k = 4q + s] = (head(k) == i)
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t)
-                        y[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, acc[m][t][s], y[t], 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) y[t] = acc[m][t];
-            }
-            unsigned addr[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) addr[s] = strip + ((unsigned)mq[m][s] & ~15u);           // the run's target row, or a dummy
-            f32x2 v[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) asm volatile("ds_read_b64 %0, %1" : "=v"(v[s]) : "v"(addr[s]) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const f32x2 r = v[s] + (f32x2){y[0][s], y[1][s]};
-                asm volatile("ds_write_b64 %0, %1" :: "v"(addr[s]), "v"(r) : "memory");
+                for (int t = 0; t < NTW; ++t) acc[m][t][s] = fmaf(part[m][t][s], f, ph == 0 ? bias_v[t] : acc[m][t][s]);
             }
         }
     };
@@ -351,50 +383,51 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     //               words are published together with its phase-0 tile, one interval before the consumers need them.
     if (producer) {
         i32x4 stgA[IPW], stgB[IPW];                    // phase-0 / phase-1 stages in flight
-        HxChunk chI = decode(load_desc(0), 0), chN = decode(load_desc(1), 1);
-        i32x2 dNN = load_desc(2);
         Words wdI{0, 0}, wdN{0, 0};
         Scales scN{1.f, 1.f};
-        if (chI.rows) {
+        HxChunk chI{0, 0, 1, 0}, chN{0, 0, 1, 0};
+        i32x2 dNN{0, 0};
+        if (nchunks > 0) {
+            chI = decode(load_desc(0));
+            chN = decode(load_desc(1));
+            dNN = load_desc(2);
             wdI = load_words(chI);
-            if (chN.rows) wdN = load_words(chN);
+            wdN = load_words(chN);
             const Scales scI = load_scales(chI, wdI);
             stage_load(stgA, chI, 0, wdI);
             stage_load(stgB, chI, 1, wdI);
-            stage_commit(stgA, a_tile(0), chI.rows);
+            stage_commit(stgA, a_tile(0));
             publish_rows(chI, wdI, scI, chunk_meta(0));
         }
-        for (int k = 0; k < nchunks; ++k) {            // chI = chunk k, chN = chunk k + 1
+        for (int k = 0; k < nchunks; ++k) {            // chI = chunk k, chN = chunk k + 1 (past the end: see decode)
             __syncthreads();                           // interval 2k
             HX_STAMP(0);
-            if (chN.rows) {
-                scN = load_scales(chN, wdN);
-                stage_load(stgA, chN, 0, wdN);
-            }
+            scN = load_scales(chN, wdN);
+            stage_load(stgA, chN, 0, wdN);
             HX_STAMP(2);
-            stage_commit(stgB, a_tile(1), chI.rows);
+            stage_commit(stgB, a_tile(1));
             HX_STAMP(3);
             __syncthreads();                           // interval 2k + 1
             HX_STAMP(0);
-            if (chN.rows) {
-                stage_load(stgB, chN, 1, wdN);
-                HX_STAMP(2);
-                stage_commit(stgA, a_tile(0), chN.rows);
-                publish_rows(chN, wdN, scN, chunk_meta(k + 1));
-            }
+            stage_load(stgB, chN, 1, wdN);
+            HX_STAMP(2);
+            stage_commit(stgA, a_tile(0));
+            publish_rows(chN, wdN, scN, chunk_meta(k + 1));
             chI = chN;
             wdI = wdN;
-            chN = decode(dNN, k + 2);
-            if (chN.rows) wdN = load_words(chN);
+            chN = decode(dNN);
+            wdN = load_words(chN);
             dNN = load_desc(k + 3);
             HX_STAMP(3);
         }
         __syncthreads();
     } else {
-        HxChunk ch = decode(load_desc(0), 0);
-        i32x2 dn = load_desc(1);
+        HxChunk ch{0, 0, 1, 0};
+        i32x2 dn{0, 0};
         float bias_v[NTW] = {};
-        if (ch.rows) {
+        if (nchunks > 0) {
+            ch = decode(load_desc(0));
+            dn = load_desc(1);
 #pragma unroll
             for (int j = 0; j < KS; ++j) load_b_step(ch.r, 0, j);
         }
@@ -406,19 +439,15 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
             const float wscale = *hx_at<float>(Wsplit, wsc_off + (uint32_t)(((dbg & 2) ? 0 : ch.r) + vzero) * 4u);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) bias_v[t] = *hx_at<float>(bias, (uint32_t)(ch.r * D + (tw * NTW + t) * 16 + c16) * 4u);
-            const HxChunk nx = decode(dn, k + 1);
-            compute_stage(mt, 0, a_tile(0), meta, wscale, ch.r, 1, true);
+            const HxChunk nx = decode(dn);
+            compute_stage(mt, 0, a_tile(0), meta, wscale, ch.r, 1, bias_v);
             HX_STAMP(1);
             __syncthreads();                           // interval 2k + 1: phase 1, then the chunk's rows join the sums
             HX_STAMP(0);
-            compute_stage(mt, 1, a_tile(1), meta, wscale, nx.r, 0, nx.rows != 0);
+            compute_stage(mt, 1, a_tile(1), meta, wscale, nx.r, 0, bias_v);
             dn = load_desc(k + 2);
             HX_STAMP(1);
-#pragma unroll
-            for (int m = 0; m < MTC; ++m)
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[m][t] = acc[m][t] + bias_v[t];   // bias[r] once per edge row
-            if (!(dbg & 8)) scatter_chunk(mt, meta);
+            if (!(dbg & 8) && !(GHF_EXP & 8)) scatter_chunk(meta, ch.cross != 0);
             ch = nx;
             HX_STAMP(4);
         }
