@@ -424,10 +424,18 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     } else {
         HxChunk ch{0, 0, 1, 0};
         i32x2 dn{0, 0};
-        float bias_v[NTW] = {};
+        // a chunk's small per-relation words (weight scale, bias) are requested one chunk ahead: a load issued at the
+        // start of the stage that needs it at its end sat in the CU's memory queue longer than the stage's MFMAs take
+        float bias_v[NTW] = {}, bias_n[NTW] = {}, wscale = 1.f, wscale_n = 1.f;
+        auto load_rel_words = [&](int r, float& ws, float (&bv)[NTW]) {
+            ws = *hx_at<float>(Wsplit, wsc_off + (uint32_t)((((dbg & 2) || (GHF_EXP & 32)) ? 0 : r) + vzero) * 4u);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[t] = *hx_at<float>(bias, (uint32_t)(r * D + (tw * NTW + t) * 16 + c16) * 4u);
+        };
         if (nchunks > 0) {
             ch = decode(load_desc(0));
             dn = load_desc(1);
+            load_rel_words(ch.r, wscale, bias_v);
 #pragma unroll
             for (int j = 0; j < KS; ++j) load_b_step(ch.r, 0, j);
         }
@@ -436,19 +444,20 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
             const int* meta = chunk_meta(k);
             __syncthreads();                           // interval 2k: phase 0
             HX_STAMP(0);
-            const float wscale = *hx_at<float>(Wsplit, wsc_off + (uint32_t)(((dbg & 2) ? 0 : ch.r) + vzero) * 4u);
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) bias_v[t] = *hx_at<float>(bias, (uint32_t)(ch.r * D + (tw * NTW + t) * 16 + c16) * 4u);
             const HxChunk nx = decode(dn);
             compute_stage(mt, 0, a_tile(0), meta, wscale, ch.r, 1, bias_v);
             HX_STAMP(1);
             __syncthreads();                           // interval 2k + 1: phase 1, then the chunk's rows join the sums
             HX_STAMP(0);
+            dn = load_desc(k + 2);                     // BEFORE this stage's B refills: its use then waits for nothing younger
+            load_rel_words(nx.r, wscale_n, bias_n);
             compute_stage(mt, 1, a_tile(1), meta, wscale, nx.r, 0, bias_v);
-            dn = load_desc(k + 2);
             HX_STAMP(1);
             if (!(dbg & 8) && !(GHF_EXP & 8)) scatter_chunk(meta, ch.cross != 0);
             ch = nx;
+            wscale = wscale_n;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bias_v[t] = bias_n[t];
             HX_STAMP(4);
         }
         __syncthreads();
