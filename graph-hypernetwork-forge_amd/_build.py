@@ -21,14 +21,17 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 SOURCES = ["capi.hip", "plan.hip", "weightgen.hip", "input_proj.hip", "message_generic.hip", "message_mfma.hip", "message_pp.hip", "message_sx.hip", "message_hx.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ghf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
-if VARIANT == "stamps":
+import re as _re
+if "stamps" in VARIANT:
     FLAGS.append("-DGHF_STAMPS")
-elif VARIANT == "ablate":
+if VARIANT == "ablate":
     FLAGS.append("-DGHF_ABLATE")
-elif VARIANT.startswith("exp"):
+_m = _re.search(r"exp(\d+)", VARIANT)
+if _m:
     # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags
-    # of the "ablate" build they add no branches, so what is left runs exactly as in the product
-    FLAGS.append("-DGHF_EXP=" + VARIANT[3:])
+    # of the "ablate" build they add no branches, so what is left runs exactly as in the product ("stampsexp<mask>"
+    # combines them with the stamps)
+    FLAGS.append("-DGHF_EXP=" + _m.group(1))
 
 
 def hipcc_path() -> str:

@@ -69,7 +69,7 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #endif
 
 // Compile-time ablations (GHF_VARIANT=exp<mask>, timing only, wrong results): 1 no B refills, 2 no gathers, 4 no main
-// MFMAs, 8 no scatter, 16 gather one hot row, 32 one relation's weights
+// MFMAs, 8 no scatter, 16 gather one hot row, 32 one relation's weights, 64 no segment-sum MFMAs, 128 no LDS read-add-write
 #ifndef GHF_EXP
 #define GHF_EXP 0
 #endif
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
         const i32x4 runs = *(const i32x4*)(meta + CR);
 #pragma unroll
         for (int m = 0; m < MTC; ++m) {
-            if (__builtin_amdgcn_readfirstlane(runs[m])) {
+            if (__builtin_amdgcn_readfirstlane(runs[m]) && !(GHF_EXP & 64)) {
                 f32x4 y[NTW];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) y[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -301,6 +301,13 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
                 asm volatile("ds_write_b64 %0, %1" :: "v"(addr[m][s]), "v"(r) : "memory");
             }
         };
+        if (GHF_EXP & 128) {                            // keep the rows alive (no dead-code elimination of the MFMAs), skip the LDS part
+#pragma unroll
+            for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) asm volatile("" :: "v"(acc[m][t]));
+            return;
+        }
         if (!in_order) {                                // no run continues into the next tile: the tiles touch disjoint rows
 #pragma unroll
             for (int m = 0; m < MTC; ++m) rd(m);
@@ -342,7 +349,14 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
             for (int m = 0; m < MTC; ++m) {
                 const int p = j * MTC + m, cur = p % 3;
                 if (p + 2 < KS * MTC) lda((p + 2) / MTC, (p + 2) % MTC, a[(p + 2) % 3]);
-                if (m < mt && !(dbg & 4) && !(GHF_EXP & 4)) {
+                if (GHF_EXP & 4) {                                          // no MFMAs, but their operands stay alive (no DCE of the loads)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) asm volatile("" :: "v"(a[cur][pl]));
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) asm volatile("" :: "v"(b[j][t][pl]));
+                } else if (m < mt && !(dbg & 4)) {
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
                         auto fma = [&](int pa, int pb) {
