@@ -26,6 +26,9 @@ if "stamps" in VARIANT:
     FLAGS.append("-DGHF_STAMPS")
 if VARIANT == "ablate":
     FLAGS.append("-DGHF_ABLATE")
+_b = _re.search(r"baux(\d+)", VARIANT)
+if _b:
+    FLAGS.append("-DGHF_B_AUX=" + _b.group(1))
 _m = _re.search(r"exp(\d+)", VARIANT)
 if _m:
     # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags

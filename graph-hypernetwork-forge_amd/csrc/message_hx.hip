@@ -73,6 +73,9 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #ifndef GHF_EXP
 #define GHF_EXP 0
 #endif
+#ifndef GHF_B_AUX
+#define GHF_B_AUX 0          // cache policy bits of the weight loads (experiment)
+#endif
 
 template <int D> struct HxCfg;
 template <> struct HxCfg<128> { static constexpr int BN = 216, MTC = 3; };   // 159 KB LDS: 1 workgroup/CU
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
-                b[j][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * (NPL * 1024), 0);
+                b[j][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * (NPL * 1024), GHF_B_AUX);
     };
 
     f32x4 acc[MTC][NTW];
