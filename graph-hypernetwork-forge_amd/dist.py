@@ -117,6 +117,12 @@ class ShardedHyperGNN:
         lo, hi = spec.chunk_rows(c)
         whole = buf[lo:hi]
         mine = buf[lo + spec.rank * spec.S: lo + (spec.rank + 1) * spec.S]
+        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo moves host memory only: bounce (this is how the multi-rank GPU test runs two ranks on one card)
+            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu(), group=self.group)
+            whole.copy_(torch.cat(parts), non_blocking=False)
+            return
         try:
             dist.all_gather_into_tensor(whole, mine, group=self.group)
         except (RuntimeError, NotImplementedError):          # backends without the fused form
