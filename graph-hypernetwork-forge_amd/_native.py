@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 GHF_FLAG_NO_TAIL = 1
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
@@ -43,7 +43,8 @@ SIGNATURES = {
                               _vp, _vp]),
     "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                  _vp, _vp, _vp, _vp]),
-    "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "ghf_text_encode_fwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ghf_message_layer_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
                                      _vp, _vp, _vp, _i32,
                                      _vp, _vp, _f32, _i64, _i64, _vp, _vp, _i32, _vp]),
@@ -188,7 +189,20 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
     return W_msg, W_self, bias
 
 
-def input_proj_fwd(x: torch.Tensor, W_in: torch.Tensor, b_in: torch.Tensor, out: Optional[torch.Tensor] = None):
+def text_encode_fwd(ids: torch.Tensor, lens: torch.Tensor, char_emb: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[U, Lmax] int32 ids + [U] lengths -> [U, T] text embeddings (reference TextEncoder, all strings at once)."""
+    ids = _req(ids, torch.int32, "ids")
+    lens = _req(lens, torch.int32, "lens")
+    E, Wt, bt = (_req(t, torch.float32, n) for t, n in ((char_emb, "char_emb.weight"), (W, "proj.weight"), (b, "proj.bias")))
+    U, Lmax = ids.shape
+    out = torch.empty(U, Wt.size(0), dtype=torch.float32, device=ids.device)
+    _check(load().ghf_text_encode_fwd(_ptr(ids), _ptr(lens), U, Lmax, _ptr(E), E.size(0), E.size(1), _ptr(Wt), _ptr(bt),
+                                      Wt.size(0), _ptr(out), _stream()), "ghf_text_encode_fwd")
+    return out
+
+
+def input_proj_fwd(x: torch.Tensor, W_in: torch.Tensor, b_in: torch.Tensor, out: Optional[torch.Tensor] = None,
+                   h_split: Optional[torch.Tensor] = None, split_layout: int = 0):
     lib = load()
     x = _req(x, torch.float32, "node_features")
     W = _req(W_in, torch.float32, "input_proj.weight")
@@ -198,8 +212,17 @@ def input_proj_fwd(x: torch.Tensor, W_in: torch.Tensor, b_in: torch.Tensor, out:
     if W.size(1) != F:
         raise ValueError(f"node_features has {F} columns but input_proj expects {W.size(1)}")
     h0 = torch.empty(N, d, dtype=torch.float32, device=x.device) if out is None else out
-    _check(lib.ghf_input_proj_fwd(_ptr(x), _ptr(W), _ptr(b), N, F, d, _ptr(h0), _stream()), "ghf_input_proj_fwd")
+    _check(lib.ghf_input_proj_fwd(_ptr(x), _ptr(W), _ptr(b), N, F, d, _ptr(h0), _ptr(h_split), split_layout, _stream()),
+           "ghf_input_proj_fwd")
     return h0
+
+
+def alloc_split(N: int, d: int, wlayout: int, device) -> torch.Tensor:
+    """Uninitialised buffer for the split form of an [N, d] matrix (ghf_split_rows_bytes)."""
+    nbytes = load().ghf_split_rows_bytes(N, d, wlayout)
+    if nbytes == 0:
+        raise ValueError(f"weight layout {wlayout} gathers h itself")
+    return torch.empty((N, 3, d) if wlayout == WLAYOUT_SPLIT3 else (nbytes // 2,), dtype=torch.int16, device=device)
 
 
 def split_rows(h: torch.Tensor, wlayout: int, out: Optional[torch.Tensor] = None, row0: int = 0,
@@ -210,10 +233,7 @@ def split_rows(h: torch.Tensor, wlayout: int, out: Optional[torch.Tensor] = None
     h = _req(h, torch.float32, "h")
     N, d = h.shape
     if out is None:
-        nbytes = lib.ghf_split_rows_bytes(N, d, wlayout)
-        if nbytes == 0:
-            raise ValueError(f"weight layout {wlayout} gathers h itself")
-        out = torch.empty((N, 3, d) if wlayout == WLAYOUT_SPLIT3 else (nbytes // 2,), dtype=torch.int16, device=h.device)
+        out = alloc_split(N, d, wlayout, h.device)
     rows = N - row0 if rows is None else rows
     _check(lib.ghf_split_rows(_ptr(h), N, d, row0, rows, wlayout, _ptr(out), _stream()), "ghf_split_rows")
     return out

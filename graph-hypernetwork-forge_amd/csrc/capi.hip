@@ -94,10 +94,16 @@ int ghf_weightgen_fwd(const float* text_emb, const float* const* head_params, co
                             hidden_ws, W_msg, W_self, bias, (hipStream_t)stream);
 }
 
+int ghf_text_encode_fwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
+                        const float* W, const float* b, int T, float* out, void* stream) {
+    GHF_REQUIRE(ids && lens && char_emb && W && b && out, "text_encode_fwd: null pointer argument");
+    return launch_text_encode(ids, lens, U, Lmax, char_emb, V, C, W, b, T, out, (hipStream_t)stream);
+}
+
 int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
-                       float* h0, void* stream) {
+                       float* h0, void* h_split, int split_layout, void* stream) {
     GHF_REQUIRE(x && W_in && b_in && h0, "input_proj_fwd: null pointer argument");
-    return launch_input_proj(x, W_in, b_in, N, F, d, h0, (hipStream_t)stream);
+    return launch_input_proj(x, W_in, b_in, N, F, d, h0, h_split, split_layout, (hipStream_t)stream);
 }
 
 size_t ghf_split_rows_bytes(int64_t N, int d, int wlayout) {

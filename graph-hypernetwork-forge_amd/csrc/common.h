@@ -110,8 +110,10 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream);
 
+int launch_text_encode(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* E, int V, int C,
+                       const float* W, const float* b, int T, float* out, hipStream_t stream);
 int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
-                      float* h0, hipStream_t stream);
+                      float* h0, void* h_split, int split_layout, hipStream_t stream);
 
 // x = p[0] + p[1] + p[2] exactly, p[i] = the i-th group of 8 significand bits as a bf16 bit pattern (truncation)
 __device__ __forceinline__ void split3_pieces(float x, uint16_t (&p)[3]) {

@@ -14,10 +14,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int IP_MT = 2;       // m-tiles (16 rows each) per wave
 
-template <int NT>  // n-tiles of 16 output columns: d = 16*NT
+// SPLIT: also write the rows in GHF_WLAYOUT_SPLIT2H form (ghf_split_rows) for the first message layer's gathers:
+// a row lives in the 16 lanes of one DPP row, so its largest magnitude is four DPP steps away.
+template <int NT, bool SPLIT>  // n-tiles of 16 output columns: d = 16*NT
 __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t N, int F,
-                                                              float* __restrict__ h0) {
+                                                              float* __restrict__ h0, char* __restrict__ h_split) {
     constexpr int D = 16 * NT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -60,9 +62,35 @@ __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t r = row_base + 16 * m + 4 * q + s;
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = fmaxf(acc[m][t][s], 0.f);
+            float up = 1.f;
+            if (SPLIT) {                                  // (all lanes take part in the reduction)
+                float mx = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mx = fmaxf(mx, v[t]);
+                mx = fmaxf(mx, dpp_take<0xB1, 0xF>(mx));
+                mx = fmaxf(mx, dpp_take<0x4E, 0xF>(mx));
+                mx = fmaxf(mx, dpp_take<0x141, 0xF>(mx));
+                mx = fmaxf(mx, dpp_take<0x140, 0xF>(mx));  // every lane of the 16 holds the row's maximum
+                const int sh = split2h_shift(mx);
+                up = pow2f(sh);
+                if (r < N && c16 == 0) *(float*)(h_split + (size_t)N * (4 * D) + (size_t)r * 4) = pow2f(-sh);
+            }
             if (r < N) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) h0[(size_t)r * D + 16 * t + c16] = fmaxf(acc[m][t][s], 0.f);
+                for (int t = 0; t < NT; ++t) h0[(size_t)r * D + 16 * t + c16] = v[t];
+                if (SPLIT) {
+                    _Float16* __restrict__ sp = (_Float16*)(h_split + (size_t)r * (4 * D));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        _Float16 hi, lo;
+                        split2h(v[t] * up, hi, lo);
+                        sp[16 * t + c16] = hi;
+                        sp[D + 16 * t + c16] = lo;
+                    }
+                }
             }
         }
 }
@@ -84,15 +112,22 @@ __global__ __launch_bounds__(256) void input_proj_simple_kernel(const float* __r
 }
 
 int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
-                      float* h0, hipStream_t stream) {
+                      float* h0, void* h_split, int split_layout, hipStream_t stream) {
     GHF_REQUIRE(N > 0 && F > 0 && d > 0, "input_proj: N, F, d must be positive");
+    GHF_REQUIRE(!h_split || split_layout == GHF_WLAYOUT_SPLIT2H || split_layout == GHF_WLAYOUT_SPLIT3,
+                "input_proj: h_split needs a split weight layout, got %d", split_layout);
+    const bool fuse = h_split && split_layout == GHF_WLAYOUT_SPLIT2H;
     const bool aligned = ((((uintptr_t)x | (uintptr_t)W_in) & 15) == 0);
     const bool mfma_ok = aligned && (F % 16) == 0 && (d % 16) == 0 && d <= 256;
     if (mfma_ok) {
         const int64_t rows_per_block = 4 * 16 * IP_MT;
         const unsigned grid = (unsigned)cdiv(N, rows_per_block);
         switch (d / 16) {
-#define GHF_IP_CASE(NT) case NT: input_proj_mfma_kernel<NT><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0); break;
+#define GHF_IP_CASE(NT)                                                                                                 \
+    case NT:                                                                                                            \
+        if (fuse) input_proj_mfma_kernel<NT, true><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, (char*)h_split);   \
+        else input_proj_mfma_kernel<NT, false><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, nullptr);             \
+        break;
             GHF_IP_CASE(1) GHF_IP_CASE(2) GHF_IP_CASE(3) GHF_IP_CASE(4) GHF_IP_CASE(5) GHF_IP_CASE(6)
             GHF_IP_CASE(7) GHF_IP_CASE(8) GHF_IP_CASE(9) GHF_IP_CASE(10) GHF_IP_CASE(11) GHF_IP_CASE(12)
             GHF_IP_CASE(13) GHF_IP_CASE(14) GHF_IP_CASE(15) GHF_IP_CASE(16)
@@ -102,6 +137,10 @@ int launch_input_proj(const float* x, const float* W_in, const float* b_in, int6
         input_proj_simple_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(x, W_in, b_in, N, F, d, h0);
     }
     GHF_LAUNCH_CHECK();
+    if (h_split && !(fuse && mfma_ok)) {                  // shapes / layouts without the fused epilogue: a separate pass
+        if (split_layout == GHF_WLAYOUT_SPLIT2H) return launch_split2h_rows(h0, N, d, 0, N, h_split, stream);
+        return launch_split3_rows(h0, N, d, 0, N, h_split, stream);
+    }
     return GHF_OK;
 }
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 4
+#define GHF_ABI_VERSION 5
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -105,10 +105,21 @@ int ghf_weightgen_fwd(const float* text_emb /* [R,T] */, const float* const* hea
                       int d_in, int d_out, int layout, float* hidden_ws,
                       float* W_msg, float* W_self, float* bias, void* stream);
 
+/* ---- text encoder ------------------------------------------------------------------
+ * Replaces models/hypergnn.py:39-81 (TextEncoder) for U strings at once:
+ *   out[u] = tanh( mean_{c < lens[u]} char_emb[ids[u][c]] . W^T + b )
+ * ids [U, Lmax] int32 = min(ord(ch), 127) per character, padded ('' is the single id 0: lens[u] >= 1); ids outside
+ * [0, V) are clamped.  char_emb [V, C], W [T, C] and b [T] as nn.Embedding / nn.Linear store them. */
+int ghf_text_encode_fwd(const int32_t* ids, const int32_t* lens, int U, int Lmax,
+                        const float* char_emb, int V, int C, const float* W, const float* b, int T,
+                        float* out /* [U,T] */, void* stream);
+
 /* ---- input projection -------------------------------------------------------------
  * Replaces models/hypergnn.py:261: h0 = relu(x @ W_in^T + b_in).  x [N,F], W_in [d,F]. */
 int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
-                       int64_t N, int F, int d, float* h0, void* stream);
+                       int64_t N, int F, int d, float* h0,
+                       void* h_split /* optional: the rows of h0 as ghf_split_rows(split_layout) would write them */,
+                       int split_layout, void* stream);
 
 /* ---- K2+K3: one message-passing layer ---------------------------------------------
  * Replaces models/hypergnn.py:281-296: per-edge weight gather, h_u @ W_msg[r] + bias[r],

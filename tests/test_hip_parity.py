@@ -69,6 +69,34 @@ def test_forward_c2_shape_sampled_rows(golden_dir):
     assert abs(np.linalg.norm(out.astype(np.float64)) - float(g["out_l2"])) <= 1e-5 * float(g["out_l2"])
 
 
+@pytest.mark.parametrize("N,F,d", [(1000, 128, 128), (77, 48, 64), (50, 20, 128)])
+def test_input_projection_and_its_fused_split(N, F, d):
+    """relu(x W^T + b) against torch, and the SPLIT2H rows the projection emits == ghf_split_rows of its output."""
+    x = torch.from_numpy(synth.normal(5, "x", (N, F))).to(DEV)
+    W = torch.from_numpy(synth.normal(5, "W", (d, F), std=0.2)).to(DEV)
+    b = torch.from_numpy(synth.normal(5, "b", (d,), std=0.5)).to(DEV)
+    hs = _native.alloc_split(N, d, _native.WLAYOUT_SPLIT2H, DEV)
+    h0 = _native.input_proj_fwd(x, W, b, h_split=hs, split_layout=_native.WLAYOUT_SPLIT2H)
+    ref = torch.relu(x.cpu() @ W.cpu().t() + b.cpu())
+    assert_close(h0.cpu().numpy(), ref.numpy(), "input projection")
+    assert torch.equal(hs, _native.split_rows(h0, _native.WLAYOUT_SPLIT2H))
+    assert torch.equal(_native.input_proj_fwd(x, W, b), h0)
+
+
+def test_text_encoder_matches_oracle():
+    """ghf_text_encode_fwd: all strings in one launch == the reference's per-string loop (empty string, characters
+    beyond ASCII clamped to 127, long and one-character strings)."""
+    from graph_hypernetwork_forge_amd.models.hypergnn import TextEncoder
+    torch.manual_seed(3)
+    enc = TextEncoder(text_dim=48, char_emb_dim=24).to(DEV).eval().requires_grad_(False)
+    params = {"text_encoder." + k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    texts = ["knows", "", "café → 東京", "a", "is parent of", "x" * 300]
+    got = enc(texts, DEV)
+    ref = O.text_encode(params, texts)
+    assert got.shape == (6, 48)
+    assert_close(got.cpu().numpy(), ref.numpy(), "text encoder", atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["g1_demo", "g1_demo_ls0", "g2_toy", "g3_mid32"])
 def test_generated_weights_match_reference(golden_dir, name):
     """K1 in NATURAL layout against the reference's per-layer (W_msg, W_self, bias)."""

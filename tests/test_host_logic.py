@@ -23,7 +23,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert set(names) == set(_native.SIGNATURES), "include/ghf.h and _native.SIGNATURES disagree"
     for n in names:
         assert hasattr(lib, n), f"libghf_hip.so does not export {n}"
-    assert lib.ghf_abi_version() == _native.ABI_VERSION == 4
+    assert lib.ghf_abi_version() == _native.ABI_VERSION == 5
 
 
 def test_abi_argument_validation_without_a_gpu():
@@ -53,7 +53,7 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.ghf_plan_max_chunks(1000, 5000, 7, 216, 48) >= 5000 // 48 + 1
     assert lib.ghf_plan_max_chunks(1000, 5000, 7, 1, 0) == 0
     assert lib.ghf_plan_max_items(1000, 5000, 7, 216, 48, 128) >= 5
-    assert lib.ghf_input_proj_fwd(None, None, None, 4, 4, 4, None, None) == -1
+    assert lib.ghf_input_proj_fwd(None, None, None, 4, 4, 4, None, None, 0, None) == -1
     assert lib.ghf_tail_fwd(None, None, None, None, 1e-5, 0, 1, 8, None, None) == -1
 
 
@@ -120,17 +120,17 @@ def test_toy_kg_matches_the_reference_fixture(golden_dir):
     assert np.array_equal(kg.node_features.numpy(), g["node_features"])
 
 
-def test_text_encoder_batched_equals_per_string_oracle():
+def test_text_encoder_tokenisation_and_no_cpu_path():
     enc = TextEncoder(text_dim=32, char_emb_dim=16).eval()
-    params = {"text_encoder." + k: v.detach().numpy() for k, v in enc.state_dict().items()}
     texts = ["knows", "", "café → 東京", "a", "is parent of"]
-    with torch.no_grad():
-        got = enc(texts, torch.device("cpu"))
-        one = enc.encode_one("knows", torch.device("cpu"))
-    ref = O.text_encode(params, texts)
-    assert got.shape == (5, 32) and torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(one, ref[0], rtol=1e-5, atol=1e-6)
-    assert enc._codes("") == [0] and enc._codes("é") == [127]
+    assert enc._codes("") == [0] and enc._codes("é") == [127]                       # reference hypergnn.py:68-70
+    ids, lens = enc._token_matrix(texts, torch.device("cpu"))
+    assert ids.dtype == torch.int32 and ids.shape == (5, 12) and lens.tolist() == [5, 1, 9, 1, 12]
+    assert ids[0, :5].tolist() == [ord(c) for c in "knows"] and ids[1].tolist() == [0] * 12
+    assert ids[2, :9].tolist() == [99, 97, 102, 127, 32, 127, 32, 127, 127]
+    assert enc._token_matrix(texts, torch.device("cpu"))[0] is ids                   # cached per list of strings
+    with torch.no_grad(), pytest.raises(RuntimeError):                                # no CPU / eager fallback
+        enc(texts, torch.device("cpu"))
 
 
 # ---- plan host logic --------------------------------------------------------------------------------
