@@ -19,6 +19,7 @@
 namespace ghf {
 
 constexpr int WG_MAX_WIDTH = 1024;   // max(T, Hh) supported by the LDS ping-pong buffers
+constexpr int WG_UNROLL = 8;         // independent dot products per wave and step in the latency-bound small kernels
 
 struct HeadPtrs {
     const float* w[3][8];     // [head][layer] weight
@@ -38,12 +39,23 @@ __global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict_
     for (int li = 0; li < num_hidden; ++li) {
         const float* __restrict__ W = P.w[head][li];
         const float* __restrict__ B = P.b[head][li];
-        // one wave per output unit: lanes stride the contraction, then a wave reduction
-        for (int j = wv; j < Hh; j += nw) {
-            float s = 0.f;
-            for (int k = lane; k < in_dim; k += 64) s = fmaf(buf[cur][k], W[(size_t)j * in_dim + k], s);
-            s = wave_sum(s);
-            if (lane == 0) buf[cur ^ 1][j] = fmaxf(s + B[j], 0.f);
+        // one wave per output unit: lanes stride the contraction, then a wave reduction; WG_UNROLL units at a time so
+        // that their weight loads are in flight together (one at a time this kernel was 64 serial L2 latencies long)
+        for (int j0 = wv * WG_UNROLL; j0 < Hh; j0 += nw * WG_UNROLL) {
+            float s[WG_UNROLL];
+#pragma unroll
+            for (int u = 0; u < WG_UNROLL; ++u) s[u] = 0.f;
+            for (int k = lane; k < in_dim; k += 64) {
+                const float xk = buf[cur][k];
+#pragma unroll
+                for (int u = 0; u < WG_UNROLL; ++u)
+                    if (j0 + u < Hh) s[u] = fmaf(xk, W[(size_t)(j0 + u) * in_dim + k], s[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < WG_UNROLL; ++u) {
+                const float t = wave_sum(s[u]);
+                if (lane == 0 && j0 + u < Hh) buf[cur ^ 1][j0 + u] = fmaxf(t + B[j0 + u], 0.f);
+            }
         }
         __syncthreads();
         cur ^= 1;
@@ -80,11 +92,21 @@ __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restr
     if (n >= n_out) return;
     const float scale = expf(log_scale[0]);
     const float bn = b3[n];
-    for (int r = 0; r < R; ++r) {
-        float s = 0.f;
-        for (int k = lane; k < Hl; k += 64) s = fmaf(z[(size_t)r * Hl + k], W3[(size_t)n * Hl + k], s);
-        s = wave_sum(s);
-        if (lane == 0) {
+    for (int r0 = 0; r0 < R; r0 += WG_UNROLL) {
+      float sv[WG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < WG_UNROLL; ++u) sv[u] = 0.f;
+      for (int k = lane; k < Hl; k += 64) {
+          const float wk = W3[(size_t)n * Hl + k];
+#pragma unroll
+          for (int u = 0; u < WG_UNROLL; ++u)
+              if (r0 + u < R) sv[u] = fmaf(z[(size_t)(r0 + u) * Hl + k], wk, sv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < WG_UNROLL; ++u) {
+        const int r = r0 + u;
+        const float s = wave_sum(sv[u]);
+        if (lane == 0 && r < R) {
             const float v = (s + bn) * scale;
             if (head == 2 || layout == GHF_WLAYOUT_NATURAL) {
                 out[(size_t)r * rstride + n] = v;
@@ -99,6 +121,7 @@ __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restr
                 out[frag16_index(r, head * d_in + i, o, d_out)] = v;
             }
         }
+      }
     }
 }
 
