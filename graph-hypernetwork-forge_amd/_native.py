@@ -51,6 +51,7 @@ SIGNATURES = {
     "ghf_split_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp]),
     "ghf_split_rows_bytes": (_sz, [_i64, _i32, _i32]),
     "ghf_weights_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "ghf_score_pairs_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
 }
 
@@ -263,6 +264,24 @@ def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Option
                                      _stream()),
            "ghf_message_layer_fwd")
     return h_out
+
+
+def score_pairs_fwd(a: torch.Tensor, b: torch.Tensor, ia: Optional[torch.Tensor] = None,
+                    ib: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """scores[i] = a[ia[i]] . b[ib[i]] (indices optional): reference score_triple with its callers' row gathers fused."""
+    a = _req(a, torch.float32, "a")
+    b = _req(b, torch.float32, "b")
+    if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(1):
+        raise ValueError(f"score_pairs: need two [rows, d] matrices of equal d, got {tuple(a.shape)} and {tuple(b.shape)}")
+    ia = None if ia is None else _req(ia, torch.int64, "ia")
+    ib = None if ib is None else _req(ib, torch.int64, "ib")
+    n = ia.numel() if ia is not None else (ib.numel() if ib is not None else a.size(0))
+    if (ia is not None and ib is not None and ia.numel() != ib.numel()) or (ia is None and ib is None and a.size(0) != b.size(0)):
+        raise ValueError("score_pairs: the two sides name different numbers of pairs")
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    _check(load().ghf_score_pairs_fwd(_ptr(a), _ptr(b), _ptr(ia), _ptr(ib), a.size(0), b.size(0), n, a.size(1), _ptr(out),
+                                      _stream()), "ghf_score_pairs_fwd")
+    return out
 
 
 def tail_fwd(agg: torch.Tensor, h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, ln_eps: float,

@@ -160,6 +160,12 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     return launch_message_mfma(a, (hipStream_t)stream);
 }
 
+int ghf_score_pairs_fwd(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,
+                        int64_t n, int d, float* scores, void* stream) {
+    GHF_REQUIRE(a && b && (scores || n == 0), "score_pairs_fwd: null pointer argument");
+    return launch_score_pairs(a, b, ia, ib, rows_a, rows_b, n, d, scores, (hipStream_t)stream);
+}
+
 int ghf_tail_fwd(const float* agg, const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps,
                  int64_t row0, int64_t rows, int d, float* h_out, void* stream) {
     GHF_REQUIRE(agg && h && ln_gamma && ln_beta && h_out, "tail_fwd: null pointer argument");

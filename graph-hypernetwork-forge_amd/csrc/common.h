@@ -110,6 +110,8 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream);
 
+int launch_score_pairs(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,
+                       int64_t n, int d, float* scores, hipStream_t stream);
 int launch_text_encode(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* E, int V, int C,
                        const float* W, const float* b, int T, float* out, hipStream_t stream);
 int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,

@@ -171,7 +171,21 @@ class HyperGNN(nn.Module):
 
     # -- convenience (reference :304-322) ---------------------------------------------------
     def score_triple(self, head_emb: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
-        return (head_emb * tail_emb).sum(dim=-1)
+        """Dot-product score of (head, tail) embeddings, ``[d]`` or ``[B, d]`` (reference :304-318)."""
+        require_inference(self, head_emb, tail_emb)
+        if head_emb.shape != tail_emb.shape or head_emb.dim() not in (1, 2):
+            raise ValueError(f"score_triple: shapes {tuple(head_emb.shape)} and {tuple(tail_emb.shape)}")
+        single = head_emb.dim() == 1
+        a = (head_emb.unsqueeze(0) if single else head_emb).float()
+        b = (tail_emb.unsqueeze(0) if single else tail_emb).float()
+        s = _native.score_pairs_fwd(a, b)
+        return s[0] if single else s
+
+    def score_edges(self, embs: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+        """``score_triple(embs[src], embs[dst])`` (the reference's call form, demo.py:90-94) without materialising the
+        two gathered ``[E, d]`` matrices."""
+        require_inference(self, embs)
+        return _native.score_pairs_fwd(embs, embs, src.to(torch.int64), dst.to(torch.int64))
 
     def num_parameters(self) -> int:
         return sum(p.numel() for p in self.parameters() if p.requires_grad)

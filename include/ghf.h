@@ -166,6 +166,14 @@ int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
                  const float* ln_gamma, const float* ln_beta, float ln_eps,
                  int64_t row0, int64_t rows, int d, float* h_out, void* stream);
 
+/* ---- link-prediction scores ------------------------------------------------------------
+ * Replaces models/hypergnn.py:304-318 (score_triple) and the row gathers of its call sites (demo.py:90-94,
+ * score_triple(embs[src], embs[dst])):  scores[i] = sum_k a[ia[i]][k] * b[ib[i]][k],  i < n.
+ * a [rows_a, d], b [rows_b, d] fp32 row-major (may be the same matrix); ia / ib int64 [n] or NULL (= i).
+ * An index outside its matrix gives NaN for that pair (the reference raises from ATen). */
+int ghf_score_pairs_fwd(const float* a, const float* b, const int64_t* ia, const int64_t* ib,
+                        int64_t rows_a, int64_t rows_b, int64_t n, int d, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,6 +180,11 @@ def layer_tail(h_new: torch.Tensor, h: torch.Tensor, gamma: torch.Tensor, beta: 
     return torch.nn.functional.layer_norm(h_new, (h_new.size(-1),), gamma, beta, eps)   # :296
 
 
+def score_triple(head_emb: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
+    """reference hypergnn.py:304-318: dot-product link score of [d] or [B, d] embeddings."""
+    return (head_emb * tail_emb).sum(dim=-1)               # :318
+
+
 # --------------------------------------------------------------------------
 # Whole forward — reference hypergnn.py:236-298
 # --------------------------------------------------------------------------

@@ -83,6 +83,27 @@ def test_input_projection_and_its_fused_split(N, F, d):
     assert torch.equal(_native.input_proj_fwd(x, W, b), h0)
 
 
+def test_score_triple_and_fused_edge_scores():
+    """reference :304-318 and its call form score_triple(embs[src], embs[dst]) (demo.py:90-94)."""
+    model = HyperGNN(text_dim=16, node_feat_dim=8, hidden_dim=128, num_layers=1).to(DEV).eval().requires_grad_(False)
+    N, E, d = 5000, 40000, 128
+    embs = torch.from_numpy(synth.normal(9, "embs", (N, d))).to(DEV)
+    src = torch.from_numpy(synth.randint(9, "s", E, N)).to(DEV)
+    dst = torch.from_numpy(synth.randint(9, "d", E, N)).to(DEV)
+    ref = O.score_triple(embs.cpu()[src.cpu()], embs.cpu()[dst.cpu()])
+    assert_close(model.score_edges(embs, src, dst).cpu().numpy(), ref.numpy(), "score_edges", atol=1e-4)
+    assert_close(model.score_triple(embs[src], embs[dst]).cpu().numpy(), ref.numpy(), "score_triple [B, d]", atol=1e-4)
+    one = model.score_triple(embs[3], embs[7])
+    assert one.dim() == 0 and abs(one.item() - float(O.score_triple(embs[3].cpu(), embs[7].cpu()))) < 1e-4
+    # odd widths take the scalar path; an out-of-range index gives NaN, not a fault
+    e20 = torch.from_numpy(synth.normal(9, "e20", (64, 20))).to(DEV)
+    assert_close(_native.score_pairs_fwd(e20, e20).cpu().numpy(), (e20.cpu() ** 2).sum(-1).numpy(), "d = 20", atol=1e-5)
+    bad = _native.score_pairs_fwd(embs, embs, torch.tensor([0, N], device=DEV), torch.tensor([1, 2], device=DEV))
+    assert torch.isfinite(bad[0]) and torch.isnan(bad[1])
+    with pytest.raises(ValueError):
+        model.score_triple(embs[:3], embs[:4])
+
+
 def test_text_encoder_matches_oracle():
     """ghf_text_encode_fwd: all strings in one launch == the reference's per-string loop (empty string, characters
     beyond ASCII clamped to 127, long and one-character strings)."""
