@@ -109,6 +109,29 @@ class HyperGNN(nn.Module):
     def clear_plan_cache(self) -> None:
         self._plans.clear()
 
+    def forward_ids(self, node_features: torch.Tensor, edge_index: torch.Tensor, edge_rel_ids: torch.Tensor,
+                    relation_texts: Sequence[str]) -> torch.Tensor:
+        """``forward`` for callers that already hold relation ids: ``edge_texts[e] == relation_texts[edge_rel_ids[e]]``.
+
+        The reference's call form hands over one Python string per edge; mapping those to ids is pure host work
+        (1.5 s at 10 M edges, reference hypergnn.py:264-268).  This overload skips it: the ids
+        may live on the device, nothing O(E) runs on the host, and the plan is cached on the two tensors' identity."""
+        if edge_rel_ids.dim() != 1 or edge_index.size(1) != edge_rel_ids.numel():
+            raise ValueError(f"edge_index has {edge_index.size(1)} edges but edge_rel_ids has {edge_rel_ids.numel()} entries")
+        if node_features.dim() != 2 or node_features.size(1) != self.node_feat_dim:
+            raise ValueError(f"node_features must be [N, {self.node_feat_dim}], got {tuple(node_features.shape)}")
+        require_inference(self, node_features)
+        device, N = node_features.device, node_features.size(0)
+        texts = list(relation_texts)
+        key = ("ids", edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+               edge_rel_ids.data_ptr(), edge_rel_ids._version, str(edge_rel_ids.device), tuple(texts), N, self.hidden_dim,
+               str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = build_plan(edge_index, edge_rel_ids, texts, N, self.hidden_dim, device)   # ids out of range: IndexError
+            self._plans.put(key, plan, edge_index, (edge_rel_ids, texts))
+        return self.forward_planned(node_features, plan)
+
     # -- forward (reference :236-298) -----------------------------------------------------
     def forward(self, node_features: torch.Tensor, edge_index: torch.Tensor, edge_texts: List[str]) -> torch.Tensor:
         if edge_index.size(1) != len(edge_texts):                     # reference :252-256

@@ -522,6 +522,28 @@ def test_errors_and_cache():
     assert a.shape == (kg.num_nodes, model.hidden_dim) and torch.isfinite(a).all()
 
 
+def test_forward_ids_equals_forward(golden_dir):
+    """The pre-tokenised overload (relation ids + one string per relation) gives the forward's result."""
+    (case,) = cases.graph_cases(only=["g3_mid32"])
+    model = make_model(cases.MODELS[case.model])
+    x, ei = torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV)
+    unique, ids = relation_ids(case.edge_texts)
+    with torch.no_grad():
+        a = model(x, ei, case.edge_texts)
+        b = model.forward_ids(x, ei, torch.from_numpy(ids).to(DEV), unique)
+        c = model.forward_ids(x, ei, torch.from_numpy(ids).to(DEV), unique)
+        ids_d = torch.from_numpy(ids).to(DEV)
+        hits = model._plans.hits
+        d = model.forward_ids(x, ei, ids_d, unique)
+        e = model.forward_ids(x, ei, ids_d, unique)
+        assert model._plans.hits == hits + 1                         # same tensors: the plan is reused
+        assert torch.equal(a, b) and torch.equal(b, c) and torch.equal(c, d) and torch.equal(d, e)
+        with pytest.raises(ValueError):
+            model.forward_ids(x, ei, ids_d[:-1], unique)
+        with pytest.raises(IndexError):
+            model.forward_ids(x, ei, ids_d + len(unique), unique)
+
+
 def test_relation_order_does_not_matter():
     """Relabelling relations / shuffling edges only permutes W[r] and the summation order."""
     (case,) = cases.graph_cases(only=["g6_c3"])
