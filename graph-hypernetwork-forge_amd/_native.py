@@ -20,8 +20,9 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 GHF_FLAG_NO_TAIL = 1
+GHF_FLAG_RAW_SUM = 2
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
 WLAYOUT_FRAG16 = 1
@@ -51,6 +52,15 @@ SIGNATURES = {
     "ghf_split_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp]),
     "ghf_split_rows_bytes": (_sz, [_i64, _i32, _i32]),
     "ghf_weights_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "ghf_group_workspace_bytes": (_sz, [_i64]),
+    "ghf_group_edges": (_i32, [_vp, _i64, _i32, _vp, _sz, _vp, _vp, _vp]),
+    "ghf_tail_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ghf_colsum_workspace_floats": (_sz, [_i64, _i32]),
+    "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "ghf_relu_mask": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "ghf_transpose_batched": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "ghf_weights_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ghf_score_pairs_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
 }
@@ -281,6 +291,87 @@ def score_pairs_fwd(a: torch.Tensor, b: torch.Tensor, ia: Optional[torch.Tensor]
     out = torch.empty(n, dtype=torch.float32, device=a.device)
     _check(load().ghf_score_pairs_fwd(_ptr(a), _ptr(b), _ptr(ia), _ptr(ib), a.size(0), b.size(0), n, a.size(1), _ptr(out),
                                       _stream()), "ghf_score_pairs_fwd")
+    return out
+
+
+# ---- backward pieces (include/ghf.h: "backward of the path") ----------------------------------------------------
+
+def group_edges(rel_id: torch.Tensor, R: int):
+    """(perm [E], goff [R+1]) int64: edge ids grouped stably by relation."""
+    lib = load()
+    rel = _req(rel_id, torch.int64, "rel_id")
+    E = rel.numel()
+    ws = torch.empty(lib.ghf_group_workspace_bytes(E), dtype=torch.uint8, device=rel.device)
+    perm = torch.empty(E, dtype=torch.int64, device=rel.device)
+    goff = torch.empty(R + 1, dtype=torch.int64, device=rel.device)
+    _check(lib.ghf_group_edges(_ptr(rel), E, R, _ptr(ws), ws.numel(), _ptr(perm), _ptr(goff), _stream()), "ghf_group_edges")
+    return perm, goff
+
+
+def tail_bwd(grad_out: torch.Tensor, agg: torch.Tensor, h: torch.Tensor, gamma: torch.Tensor, eps: float, indeg: torch.Tensor):
+    """(dpre, G, T) of include/ghf.h: ghf_tail_bwd."""
+    g = _req(grad_out, torch.float32, "grad_out")
+    N, d = h.shape
+    dpre, G, T = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+    _check(load().ghf_tail_bwd(_ptr(g), _ptr(_req(agg, torch.float32, "agg")), _ptr(_req(h, torch.float32, "h")),
+                               _ptr(_req(gamma, torch.float32, "gamma")), float(eps), _ptr(indeg), N, d, _ptr(dpre), _ptr(G),
+                               _ptr(T), _stream()), "ghf_tail_bwd")
+    return dpre, G, T
+
+
+def colsum(X: torch.Tensor, mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[o] (+)= sum_v X[v][o] * (mask[v][o] > 0); accumulates when `out` is given."""
+    lib = load()
+    X = _req(X, torch.float32, "X")
+    N, d = X.shape
+    ws = torch.empty(lib.ghf_colsum_workspace_floats(N, d), dtype=torch.float32, device=X.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(d, dtype=torch.float32, device=X.device)
+    _check(lib.ghf_colsum(_ptr(X), _ptr(None if mask is None else _req(mask, torch.float32, "mask")), N, d, _ptr(ws), _ptr(out),
+                          1 if acc else 0, _stream()), "ghf_colsum")
+    return out
+
+
+def relu_mask(X: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    X = _req(X, torch.float32, "X")
+    out = torch.empty_like(X)
+    _check(load().ghf_relu_mask(_ptr(X), _ptr(_req(ref, torch.float32, "ref")), X.numel(), _ptr(out), _stream()), "ghf_relu_mask")
+    return out
+
+
+def group_outer(A: Optional[torch.Tensor], ia: Optional[torch.Tensor], B: torch.Tensor, ib: Optional[torch.Tensor],
+                goff: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[g] (+)= sum_{e in group g} A[ia[e]]^T (outer) B[ib[e]]; A None: column sums of the gathered B rows ([G, 1, db])."""
+    lib = load()
+    B = _req(B, torch.float32, "B")
+    A = None if A is None else _req(A, torch.float32, "A")
+    da, db, ng = (0 if A is None else A.size(1)), B.size(1), goff.numel() - 1
+    acc = out is not None
+    if out is None:
+        out = torch.empty(ng, max(da, 1), db, dtype=torch.float32, device=B.device)
+    _check(lib.ghf_group_outer(_ptr(A), _ptr(ia), da, _ptr(B), _ptr(ib), db, _ptr(_req(goff, torch.int64, "goff")), ng, _ptr(out),
+                               1 if acc else 0, _stream()), "ghf_group_outer")
+    return out
+
+
+def transpose_batched(x: torch.Tensor) -> torch.Tensor:
+    """[B, r, c] -> [B, c, r] (a copy)."""
+    x = _req(x, torch.float32, "x")
+    Bn, r, c = x.shape
+    out = torch.empty(Bn, c, r, dtype=torch.float32, device=x.device)
+    _check(load().ghf_transpose_batched(_ptr(x), Bn, r, c, _ptr(out), _stream()), "ghf_transpose_batched")
+    return out
+
+
+def weights_pack(top: Optional[torch.Tensor], bottom: Optional[torch.Tensor], transpose: bool, R: int, d: int, wlayout: int):
+    """[top[r]; bottom[r]] (natural [R, d, d] each, None = zeros, optionally transposed) in the kernel's weight layout."""
+    lib = load()
+    dev = (top if top is not None else bottom).device
+    out = torch.empty(lib.ghf_weights_bytes(R, d, d, wlayout) // 4, dtype=torch.float32, device=dev)
+    _check(lib.ghf_weights_pack(_ptr(None if top is None else _req(top, torch.float32, "top")),
+                                _ptr(None if bottom is None else _req(bottom, torch.float32, "bottom")), 1 if transpose else 0,
+                                R, d, wlayout, _ptr(out), _stream()), "ghf_weights_pack")
     return out
 
 

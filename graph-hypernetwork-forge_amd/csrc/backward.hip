@@ -1,0 +1,225 @@
+// backward.hip — gradients of the hot path: the pieces that are not the message kernel itself.
+//
+// The reference trains through these ops with autograd (demo.py:79-101, tests/test_hypergnn.py:183-226).  With
+//   out_v = (1/c_v) sum_{e=(u->v)} (h_u Wm[r_e] + b[r_e] + h_v Ws[r_e]),   x_v = relu(out_v + h_v),   h'_v = LN(x_v)
+// and g' = dL/dh':
+//   tail_bwd      : dpre = LN'(x) g' * [pre > 0]  (pre = out + h);  G_v = dpre_v / c_v;  T = g' * xhat (for dgamma)
+//   colsum        : dbeta = colsum(g'), dgamma = colsum(T), bias gradients of the linear layers        (deterministic)
+//   group_outer   : dWm[r] = sum_{e in r} h_u^T G_v,  dWs[r] = sum h_v^T G_v,  db[r] = sum G_v  — and the input projection's
+//                   and the weight generator's weight gradients, which are the same contraction over rows
+//   the gradient with respect to h is two more passes of the forward message kernel with transposed weights
+//   (GHF_FLAG_RAW_SUM): sum_{e->v} G_v Ws[r]^T on the forward plan, sum_{e: src=u} G_v Wm[r]^T on the reversed one.
+// First version: exact fp32 (v_mfma_f32_16x16x4_f32 / vector ALU), deterministic summation orders, any d <= 1024.
+#include "common.h"
+
+namespace ghf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BW_MAX_D = 1024;
+constexpr int BW_PER_LANE = BW_MAX_D / 64;
+
+// one wave per row
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ agg,
+                                                       const float* __restrict__ h, const float* __restrict__ gamma, float eps,
+                                                       const int32_t* __restrict__ indeg, int64_t N, int d,
+                                                       float* __restrict__ dpre, float* __restrict__ G, float* __restrict__ T) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= N) return;
+    float pre[BW_PER_LANE], x[BW_PER_LANE], gg[BW_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < BW_PER_LANE; ++c) {
+        const int o = lane + 64 * c;
+        pre[c] = x[c] = gg[c] = 0.f;
+        if (o < d) {
+            pre[c] = agg[(size_t)v * d + o] + h[(size_t)v * d + o];
+            x[c] = fmaxf(pre[c], 0.f);
+            s += x[c];
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < BW_PER_LANE; ++c)
+        if (lane + 64 * c < d) { const float t = x[c] - mean; var += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
+    float s1 = 0.f, s2 = 0.f;                            // mean(gamma g'), mean(gamma g' xhat)
+#pragma unroll
+    for (int c = 0; c < BW_PER_LANE; ++c) {
+        const int o = lane + 64 * c;
+        if (o < d) {
+            const float go = g_out[(size_t)v * d + o], xh = (x[c] - mean) * rstd;
+            gg[c] = go * gamma[o];
+            s1 += gg[c];
+            s2 += gg[c] * xh;
+            T[(size_t)v * d + o] = go * xh;
+            x[c] = xh;
+        }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+    const int deg = indeg[v];
+    const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+#pragma unroll
+    for (int c = 0; c < BW_PER_LANE; ++c) {
+        const int o = lane + 64 * c;
+        if (o < d) {
+            const float dx = rstd * (gg[c] - s1 - x[c] * s2);
+            const float dp = pre[c] > 0.f ? dx : 0.f;
+            dpre[(size_t)v * d + o] = dp;
+            G[(size_t)v * d + o] = dp * inv;
+        }
+    }
+}
+
+// out[o] = sum_v X[v][o] * (mask ? (mask[v][o] > 0) : 1), in two deterministic stages
+constexpr int CS_ROWS = 512;                              // rows per first-stage workgroup
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ X, const float* __restrict__ mask,
+                                                            int64_t N, int d, float* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < N ? r0 + CS_ROWS : N;
+    for (int o = threadIdx.x; o < d; o += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float xv = X[(size_t)r * d + o];
+            s += (!mask || mask[(size_t)r * d + o] > 0.f) ? xv : 0.f;
+        }
+        part[(size_t)blockIdx.x * d + o] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int64_t nblk, int d,
+                                                            float* __restrict__ out, int accumulate) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= d) return;
+    float s = 0.f;
+    for (int64_t b = 0; b < nblk; ++b) s += part[(size_t)b * d + o];
+    out[o] = accumulate ? out[o] + s : s;
+}
+
+// dmask[v][o] = X[v][o] * (ref[v][o] > 0)   (ReLU backward as a matrix, for the contractions below)
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ X, const float* __restrict__ ref, int64_t n,
+                                                        float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ref[i] > 0.f ? X[i] : 0.f;
+}
+
+// C[g][i][o] (+)= sum_{e in group g} A[ia[e]][i] * B[ib[e]][o],  groups = contiguous ranges goff[g] .. goff[g+1] of e.
+// One workgroup per (group, 16-row tile of i): its 4 waves take contiguous quarters of the group's edges, every wave
+// runs v_mfma_f32_16x16x4_f32 over 4 edges per step (A fragment: lane (i = l&15, k = l>>4) = A[ia[e+k]][i0+i];
+// B fragment: B[ib[e+k]][16t + (l&15)]), and the four partial tiles are added in wave order through LDS: the
+// summation order is fixed.  da == 0 means A = 1 (column sums of the gathered rows).
+template <int NTB>   // 16-column tiles of B handled per pass (db <= 16*NTB per pass)
+__global__ __launch_bounds__(256) void group_outer_kernel(const float* __restrict__ A, const int64_t* __restrict__ ia, int da,
+                                                          const float* __restrict__ B, const int64_t* __restrict__ ib, int db,
+                                                          const int64_t* __restrict__ goff, float* __restrict__ Cout,
+                                                          int o_base, int accumulate) {
+    __shared__ float red[4][16][16 * NTB + 1];
+    const int g = blockIdx.x, it = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int64_t e0 = goff[g], e1 = goff[g + 1];
+    const int64_t per = ((e1 - e0 + 3) / 4 + 3) & ~(int64_t)3;            // edges per wave, a multiple of 4
+    const int64_t w0 = e0 + w * per, w1 = (w0 + per < e1) ? w0 + per : e1;
+    const int i = it * 16 + c16;
+    const int rows_a = da > 0 ? da : 1;
+    f32x4 acc[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int64_t e = w0; e < w1; e += 4) {
+        const int64_t ek = e + q;                         // this lane's edge for both fragments
+        const bool ok = ek < w1;
+        float a = 0.f;
+        if (ok && i < rows_a) a = da > 0 ? A[(size_t)(ia ? ia[ek] : ek) * da + i] : 1.0f;
+        const int64_t rb = ok ? (ib ? ib[ek] : ek) : 0;
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            const int o = o_base + 16 * t + c16;
+            const float b = (ok && o < db) ? B[(size_t)rb * db + o] : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // D: lane holds rows 4q + s, column 16t + c16
+#pragma unroll
+    for (int t = 0; t < NTB; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) red[w][4 * q + s][16 * t + c16] = acc[t][s];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * 16 * NTB; idx += 256) {
+        const int r = idx / (16 * NTB), c = idx % (16 * NTB);
+        const int ii = it * 16 + r, o = o_base + c;
+        if (ii < rows_a && o < db) {
+            const float s = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+            float* dst = Cout + ((size_t)g * rows_a + ii) * db + o;
+            *dst = accumulate ? *dst + s : s;
+        }
+    }
+}
+
+// out[b][j][i] = in[b][i][j]
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, int rows, int cols,
+                                                                float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const float* src = in + (size_t)b * rows * cols;
+    float* dst = out + (size_t)b * rows * cols;
+    for (int k = threadIdx.x; k < 1024; k += 256) {
+        const int r = r0 + k / 32, c = c0 + k % 32;
+        if (r < rows && c < cols) tile[k / 32][k % 32] = src[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += 256) {
+        const int c = c0 + k / 32, r = r0 + k % 32;
+        if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[k % 32][k / 32];
+    }
+}
+
+int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const float* gamma, float eps, const int32_t* indeg,
+                    int64_t N, int d, float* dpre, float* G, float* T, hipStream_t stream) {
+    GHF_REQUIRE(d >= 1 && d <= BW_MAX_D, "tail_bwd: d=%d outside [1,%d]", d, BW_MAX_D);
+    if (N <= 0) return GHF_OK;
+    tail_bwd_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(g_out, agg, h, gamma, eps, indeg, N, d, dpre, G, T);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+size_t colsum_workspace_floats(int64_t N, int d) { return (size_t)cdiv(N, CS_ROWS) * d; }
+
+int launch_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, hipStream_t stream) {
+    GHF_REQUIRE(N > 0 && d > 0, "colsum: bad shape");
+    const int64_t nblk = cdiv(N, CS_ROWS);
+    colsum_stage1_kernel<<<(unsigned)nblk, 256, 0, stream>>>(X, mask, N, d, workspace);
+    GHF_LAUNCH_CHECK();
+    colsum_stage2_kernel<<<(unsigned)cdiv(d, 256), 256, 0, stream>>>(workspace, nblk, d, out, accumulate);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int launch_relu_mask(const float* X, const float* ref, int64_t n, float* out, hipStream_t stream) {
+    if (n <= 0) return GHF_OK;
+    relu_mask_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(X, ref, n, out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
+                       const int64_t* goff, int ngroups, float* C, int accumulate, hipStream_t stream) {
+    GHF_REQUIRE(da >= 0 && db > 0 && ngroups > 0, "group_outer: bad shape");
+    const int rows_a = da > 0 ? da : 1;
+    const dim3 grid((unsigned)ngroups, (unsigned)cdiv(rows_a, 16));
+    for (int o_base = 0; o_base < db; o_base += 128) {
+        group_outer_kernel<8><<<grid, 256, 0, stream>>>(A, ia, da, B, ib, db, goff, C, o_base, accumulate);
+        GHF_LAUNCH_CHECK();
+    }
+    return GHF_OK;
+}
+
+int launch_transpose_batched(const float* in, int batch, int rows, int cols, float* out, hipStream_t stream) {
+    GHF_REQUIRE(batch > 0 && rows > 0 && cols > 0 && batch < 65536, "transpose: bad shape");
+    transpose_batched_kernel<<<dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32), (unsigned)batch), 256, 0, stream>>>(in, rows, cols, out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+}  // namespace ghf

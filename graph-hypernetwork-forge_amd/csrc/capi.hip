@@ -139,7 +139,10 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
                           float* h_out, void* h_split_out, int flags, void* stream) {
     GHF_REQUIRE(h && sorted_key && sorted_src && seg_off && indeg && W_msg && bias && h_out,
                 "message_layer_fwd: null pointer argument");
+    if (flags & GHF_FLAG_RAW_SUM) flags |= GHF_FLAG_NO_TAIL;
     GHF_REQUIRE((flags & GHF_FLAG_NO_TAIL) || (ln_gamma && ln_beta), "message_layer_fwd: LayerNorm parameters missing");
+    GHF_REQUIRE(!(flags & GHF_FLAG_RAW_SUM) || block_nodes == 1 || wlayout == GHF_WLAYOUT_SPLIT2H,
+                "message_layer_fwd: GHF_FLAG_RAW_SUM is implemented by the generic and the SPLIT2H kernels");
     GHF_REQUIRE(h != h_out, "message_layer_fwd: h_out must not alias h");
     GHF_REQUIRE(N > 0 && d > 0 && R > 0 && block_nodes > 0, "message_layer_fwd: N, d, R, block_nodes must be positive");
     GHF_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= N, "message_layer_fwd: row range [%lld,+%lld) outside [0,%lld)",
@@ -158,6 +161,47 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_message_hx(a, (hipStream_t)stream);
     return launch_message_mfma(a, (hipStream_t)stream);
+}
+
+size_t ghf_group_workspace_bytes(int64_t E) { return group_workspace_bytes(E); }
+
+int ghf_group_edges(const int64_t* rel_id, int64_t E, int R, void* workspace, size_t workspace_bytes, int64_t* perm,
+                    int64_t* goff, void* stream) {
+    GHF_REQUIRE(rel_id && workspace && perm && goff, "group_edges: null pointer argument");
+    return launch_group_edges(rel_id, E, R, workspace, workspace_bytes, perm, goff, (hipStream_t)stream);
+}
+
+int ghf_tail_bwd(const float* grad_out, const float* agg, const float* h, const float* ln_gamma, float ln_eps,
+                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, void* stream) {
+    GHF_REQUIRE(grad_out && agg && h && ln_gamma && indeg && dpre && G && T, "tail_bwd: null pointer argument");
+    return launch_tail_bwd(grad_out, agg, h, ln_gamma, ln_eps, indeg, N, d, dpre, G, T, (hipStream_t)stream);
+}
+
+size_t ghf_colsum_workspace_floats(int64_t N, int d) { return colsum_workspace_floats(N, d); }
+
+int ghf_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, void* stream) {
+    GHF_REQUIRE(X && workspace && out, "colsum: null pointer argument");
+    return launch_colsum(X, mask, N, d, workspace, out, accumulate, (hipStream_t)stream);
+}
+
+int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void* stream) {
+    GHF_REQUIRE(X && ref && out, "relu_mask: null pointer argument");
+    return launch_relu_mask(X, ref, n, out, (hipStream_t)stream);
+}
+
+int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
+                    const int64_t* goff, int ngroups, float* C, int accumulate, void* stream) {
+    GHF_REQUIRE((A || da == 0) && B && goff && C, "group_outer: null pointer argument");
+    return launch_group_outer(A, ia, da, B, ib, db, goff, ngroups, C, accumulate, (hipStream_t)stream);
+}
+
+int ghf_transpose_batched(const float* in, int batch, int rows, int cols, float* out, void* stream) {
+    GHF_REQUIRE(in && out && in != out, "transpose_batched: null or aliased pointers");
+    return launch_transpose_batched(in, batch, rows, cols, out, (hipStream_t)stream);
+}
+
+int ghf_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int wlayout, float* out, void* stream) {
+    return launch_weights_pack(top, bottom, transpose, R, d, wlayout, out, (hipStream_t)stream);
 }
 
 int ghf_score_pairs_fwd(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,

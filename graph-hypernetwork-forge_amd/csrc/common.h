@@ -148,6 +148,21 @@ int launch_message_sx(const MsgArgs& a, hipStream_t stream);       // split-bf16
 bool message_sx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 int launch_combine_split(const MsgArgs& a, hipStream_t stream);     // sums the partial slots of split blocks + tail
 
+size_t group_workspace_bytes(int64_t E);
+int launch_group_edges(const int64_t* rel, int64_t E, int R, void* ws, size_t ws_bytes, int64_t* perm, int64_t* goff,
+                       hipStream_t stream);
+// backward.hip
+int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const float* gamma, float eps, const int32_t* indeg,
+                    int64_t N, int d, float* dpre, float* G, float* T, hipStream_t stream);
+size_t colsum_workspace_floats(int64_t N, int d);
+int launch_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, hipStream_t stream);
+int launch_relu_mask(const float* X, const float* ref, int64_t n, float* out, hipStream_t stream);
+int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
+                       const int64_t* goff, int ngroups, float* C, int accumulate, hipStream_t stream);
+int launch_transpose_batched(const float* in, int batch, int rows, int cols, float* out, hipStream_t stream);
+int launch_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int layout, float* out,
+                        hipStream_t stream);
+
 int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,
                 int64_t row0, int64_t rows, int d, float* h_out, hipStream_t stream);
 

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(GEN_TPB) void message_generic_kernel(
     __syncthreads();
 
     const int deg = indeg[v];
-    const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+    const float inv = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
     float* __restrict__ orow = h_out + (size_t)v * d;
     if (no_tail) {
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
     for (int v = w; v < nrows; v += 4) {
         const int64_t node = node0 + v;
         const int deg = indeg[node];
-        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        const float inv = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
         float x[COMB_MAX_PER_LANE];
         float s = 0.f;
 #pragma unroll
@@ -213,7 +213,7 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const unsigned grid = (unsigned)cdiv(a.rows, a.block_nodes);
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
                                                    a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, a.h_split_out, a.wlayout,
-                                                   (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
@@ -226,7 +226,7 @@ int launch_message_generic(const MsgArgs& a, hipStream_t stream) {
     if (a.rows <= 0) return GHF_OK;
     message_generic_kernel<<<(unsigned)a.rows, GEN_TPB, 0, stream>>>(
         a.h, a.d, a.sorted_key, a.sorted_src, a.seg_off, a.indeg, a.R, a.W_msg, a.W_self, a.bias,
-        a.ln_gamma, a.ln_beta, a.ln_eps, a.row0, a.h_out, (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+        a.ln_gamma, a.ln_beta, a.ln_eps, a.row0, a.h_out, a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

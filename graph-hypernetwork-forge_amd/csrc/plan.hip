@@ -258,4 +258,50 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
     return GHF_OK;
 }
 
+// ---- ghf_group_edges: edges grouped by relation, for the backward's per-relation contractions -------------------------
+// perm[0..E) = edge ids sorted (stably) by relation, goff[r] = first position of relation r, goff[R] = E.
+__global__ void group_keys_kernel(const int64_t* __restrict__ rel, int64_t E, int R, uint32_t* __restrict__ key, int32_t* __restrict__ val) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t r = rel[e];
+    key[e] = (r >= 0 && r < R) ? (uint32_t)r : (uint32_t)(R - 1);       // (range was checked by the plan build)
+    val[e] = (int32_t)e;
+}
+__global__ void group_finish_kernel(const uint32_t* __restrict__ skey, const int32_t* __restrict__ sval, int64_t E, int R,
+                                    int64_t* __restrict__ perm, int64_t* __restrict__ goff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) perm[i] = sval[i];
+    if (i <= R) {
+        int64_t lo = 0, hi = E;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (skey[mid] < (uint32_t)i) lo = mid + 1; else hi = mid; }
+        goff[i] = lo;
+    }
+}
+
+size_t group_workspace_bytes(int64_t E) {
+    return align_up((size_t)E * 4, 256) * 4 + align_up(sort_temp_bytes(E), 256);
+}
+
+int launch_group_edges(const int64_t* rel, int64_t E, int R, void* ws, size_t ws_bytes, int64_t* perm, int64_t* goff,
+                       hipStream_t stream) {
+    GHF_REQUIRE(E > 0 && E < (1ll << 31) && R > 0, "group_edges: bad sizes");
+    GHF_REQUIRE(ws_bytes >= group_workspace_bytes(E), "group_edges: workspace too small");
+    char* p = (char*)ws;
+    uint32_t* key = (uint32_t*)p;  p += align_up((size_t)E * 4, 256);
+    int32_t* val = (int32_t*)p;    p += align_up((size_t)E * 4, 256);
+    uint32_t* skey = (uint32_t*)p; p += align_up((size_t)E * 4, 256);
+    int32_t* sval = (int32_t*)p;   p += align_up((size_t)E * 4, 256);
+    size_t tb = sort_temp_bytes(E);
+    const int gb = (int)((E + 255) / 256);
+    group_keys_kernel<<<gb, 256, 0, stream>>>(rel, E, R, key, val);
+    GHF_LAUNCH_CHECK();
+    int bits = 1;
+    while ((1ll << bits) < R) ++bits;
+    GHF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(p, tb, key, skey, val, sval, (int)E, 0, bits, stream));   // stable
+    const int64_t n = E > R + 1 ? E : R + 1;
+    group_finish_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(skey, sval, E, R, perm, goff);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 }  // namespace ghf

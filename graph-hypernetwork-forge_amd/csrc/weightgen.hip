@@ -253,6 +253,36 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
     }
 }
 
+// ghf_weights_pack: [W_top[r]; W_bottom[r]] (each [d,d] natural, optionally transposed, NULL = zeros) -> the [R][2d][d]
+// fp32 matrix the in-place packer takes.  Used for the backward passes' transposed weights.
+__global__ __launch_bounds__(256) void wg_combine_kernel(const float* __restrict__ top, const float* __restrict__ bottom,
+                                                         int transpose, int d, float* __restrict__ out) {
+    const int r = blockIdx.y;
+    const int n = 2 * d * d;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int kk = idx / d, o = idx - kk * d;
+        const float* src = kk < d ? top : bottom;
+        const int k = kk < d ? kk : kk - d;
+        float v = 0.f;
+        if (src) v = transpose ? src[((size_t)r * d + o) * d + k] : src[((size_t)r * d + k) * d + o];
+        out[(size_t)r * n + idx] = v;
+    }
+}
+
+int launch_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int layout, float* out,
+                        hipStream_t stream) {
+    GHF_REQUIRE(R > 0 && d > 0 && out, "weights_pack: bad arguments");
+    GHF_REQUIRE(layout == GHF_WLAYOUT_SPLIT2H, "weights_pack: layout %d is not packed from natural matrices here", layout);
+    GHF_REQUIRE((d % 32) == 0 && (size_t)2 * d * d * 4 <= 128 * 1024, "weights_pack: SPLIT2H needs d %% 32 == 0, d <= 128");
+    wg_combine_kernel<<<dim3(32, (unsigned)R), 256, 0, stream>>>(top, bottom, transpose, d, out);
+    GHF_LAUNCH_CHECK();
+    const size_t lds = (size_t)2 * d * d * 4;
+    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)wg_pack2h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    wg_pack2h_kernel<<<R, 1024, lds, stream>>>(out, out + (size_t)R * 2 * d * d, d);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream) {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 5
+#define GHF_ABI_VERSION 6
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -38,6 +38,7 @@ extern "C" {
 
 /* ghf_message_layer_fwd flags */
 #define GHF_FLAG_NO_TAIL  1   /* write sum_e(...) / max(indeg,1) only: skip residual+ReLU+LayerNorm */
+#define GHF_FLAG_RAW_SUM  2   /* (implies NO_TAIL) write sum_e(...) itself, no division: the backward passes */
 
 /* Weight layouts produced by ghf_weightgen_fwd and consumed by ghf_message_layer_fwd */
 #define GHF_WLAYOUT_NATURAL 0 /* W_msg[R][d_in][d_out], W_self[R][d_in][d_out] row-major, as the reference returns them */
@@ -165,6 +166,32 @@ size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout);
 int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
                  const float* ln_gamma, const float* ln_beta, float ln_eps,
                  int64_t row0, int64_t rows, int d, float* h_out, void* stream);
+
+/* ---- backward of the path (the reference trains through it with autograd: demo.py:79-101) ----------
+ * With out_v = (1/c_v) sum_e(h_u Wm[r] + b[r] + h_v Ws[r]), x = relu(out + h), h' = LayerNorm(x), g' = dL/dh':
+ *   ghf_tail_bwd   : dpre = dL/d(out+h) (also the residual's share of dL/dh), G_v = dpre_v / c_v, T = g' * xhat
+ *                    (dgamma = colsum(T), dbeta = colsum(g'));  agg is the forward's GHF_FLAG_NO_TAIL output
+ *   ghf_group_outer: C[g][i][o] (+)= sum_{e in goff[g]..goff[g+1]} A[ia[e]][i] * B[ib[e]][o]; ia / ib NULL = e itself,
+ *                    da == 0: A = 1 (C is [ngroups][1][db]).  dWm[r] = sum h_u^T G_v, dWs[r], db[r], and the Linear
+ *                    layers' weight gradients.  Summation order fixed: reproducible.
+ *   ghf_colsum     : out[o] (+)= sum_v X[v][o] * (mask ? mask[v][o] > 0 : 1); workspace: ghf_colsum_workspace_floats
+ *   ghf_relu_mask  : out = X * (ref > 0);   ghf_transpose_batched: out[b][j][i] = in[b][i][j]
+ *   ghf_weights_pack: [top[r] ; bottom[r]] ([d,d] natural each, optionally transposed, NULL = zeros) -> weight layout
+ *                    (the gradient with respect to h is ghf_message_layer_fwd with GHF_FLAG_RAW_SUM on transposed
+ *                    weights: sum_{e->v} G_v Ws[r]^T on the plan, sum_{e: src=u} G_v Wm[r]^T on the reversed plan). */
+/* Edge ids grouped (stably) by relation: perm [E], goff [R+1] (goff[r] = first position of relation r). */
+size_t ghf_group_workspace_bytes(int64_t E);
+int ghf_group_edges(const int64_t* rel_id, int64_t E, int R, void* workspace, size_t workspace_bytes,
+                    int64_t* perm, int64_t* goff, void* stream);
+int ghf_tail_bwd(const float* grad_out, const float* agg, const float* h, const float* ln_gamma, float ln_eps,
+                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, void* stream);
+size_t ghf_colsum_workspace_floats(int64_t N, int d);
+int ghf_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, void* stream);
+int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void* stream);
+int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
+                    const int64_t* goff, int ngroups, float* C, int accumulate, void* stream);
+int ghf_transpose_batched(const float* in, int batch, int rows, int cols, float* out, void* stream);
+int ghf_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int wlayout, float* out, void* stream);
 
 /* ---- link-prediction scores ------------------------------------------------------------
  * Replaces models/hypergnn.py:304-318 (score_triple) and the row gathers of its call sites (demo.py:90-94,

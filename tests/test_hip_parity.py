@@ -473,6 +473,36 @@ def test_split_hub_blocks_match_oracle(d, kernel):
         assert (part[:bn] == 7.0).all() and (part[4 * bn:] == 7.0).all()
 
 
+@pytest.mark.parametrize("d,N,E,R,kind", [(20, 300, 2500, 5, "powerlaw"), (128, 1200, 9000, 6, "uniform"),
+                                          (128, 500, 6000, 3, "powerlaw")])
+def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind):
+    """Gradients of one layer with respect to h, W_msg, W_self, bias, gamma, beta: HIP backward (autograd.py) against
+    torch.autograd through the oracle's restatement of the reference ops."""
+    from graph_hypernetwork_forge_amd.autograd import MessageLayerFn, build_train_plan
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=300 + d + R, kind=kind)
+    th = torch.from_numpy
+    dev = lambda a: th(a).to(DEV).requires_grad_(True)                                      # noqa: E731
+    plan = build_plan(th(ei).to(DEV), th(rel).to(DEV), [""] * R, N, d, DEV)
+    tp = build_train_plan(th(ei).to(DEV), th(rel).to(DEV), plan, d, DEV)
+    args = [dev(a) for a in (h, Wm, Ws, b, gamma, beta)]
+    out = MessageLayerFn.apply(*args, 1e-5, tp)
+    gout = th(synth.normal(77, "gout", (N, d)))
+    out.backward(gout.to(DEV))
+    # oracle: same function in torch on the CPU, differentiated by autograd
+    ref_in = [th(a).clone().requires_grad_(True) for a in (h, Wm, Ws, b, gamma, beta)]
+    agg = O.message_passing_factorised(ref_in[0], th(ei), th(rel), ref_in[1], ref_in[2], ref_in[3])
+    ref = O.layer_tail(agg, ref_in[0], ref_in[4], ref_in[5])
+    assert_close(out.detach().cpu().numpy(), ref.detach().numpy(), "training forward")
+    ref.backward(gout)
+    for name, got, want in zip(("h", "W_msg", "W_self", "bias", "gamma", "beta"), args, ref_in):
+        gw, gg = want.grad.numpy(), got.grad.cpu().numpy()
+        scale = float(np.abs(gw).max())
+        assert np.allclose(gg, gw, rtol=2e-4, atol=2e-5 * max(scale, 1.0)), \
+            f"d{name}: max abs err {np.abs(gg - gw).max():.3e} at scale {scale:.3e}"
+        rel_l2 = np.linalg.norm((gg - gw).astype(np.float64)) / max(np.linalg.norm(gw.astype(np.float64)), 1e-30)
+        assert rel_l2 < 2e-5, f"d{name}: relative L2 {rel_l2:.3e}"
+
+
 def test_row_range_only_touches_its_rows(kernel):
     d, N, E, R = 128, 2000, 20000, 16
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=5, kind="uniform")
