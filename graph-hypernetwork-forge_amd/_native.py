@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
@@ -58,7 +58,13 @@ SIGNATURES = {
     "ghf_colsum_workspace_floats": (_sz, [_i64, _i32]),
     "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ghf_relu_mask": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "ghf_add3": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "ghf_dot": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "ghf_weightgen_acts": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ghf_text_encode_bwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_transpose_batched": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ghf_weights_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ghf_score_pairs_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
@@ -342,17 +348,120 @@ def relu_mask(X: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
 
 def group_outer(A: Optional[torch.Tensor], ia: Optional[torch.Tensor], B: torch.Tensor, ib: Optional[torch.Tensor],
                 goff: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C[g] (+)= sum_{e in group g} A[ia[e]]^T (outer) B[ib[e]]; A None: column sums of the gathered B rows ([G, 1, db])."""
+    """C[g] (+)= sum_{e in goff[g]..goff[g+1]} A[ia[e]]^T (outer) B[ib[e]]; A None: column sums of the gathered B rows
+    ([G, 1, db])."""
     lib = load()
     B = _req(B, torch.float32, "B")
     A = None if A is None else _req(A, torch.float32, "A")
+    goff = _req(goff, torch.int64, "goff")
     da, db, ng = (0 if A is None else A.size(1)), B.size(1), goff.numel() - 1
     acc = out is not None
     if out is None:
         out = torch.empty(ng, max(da, 1), db, dtype=torch.float32, device=B.device)
-    _check(lib.ghf_group_outer(_ptr(A), _ptr(ia), da, _ptr(B), _ptr(ib), db, _ptr(_req(goff, torch.int64, "goff")), ng, _ptr(out),
-                               1 if acc else 0, _stream()), "ghf_group_outer")
+    _check(lib.ghf_group_outer(_ptr(A), _ptr(ia), da, _ptr(B), _ptr(ib), db, goff.data_ptr(), goff.data_ptr() + 8, ng,
+                               _ptr(out), 1 if acc else 0, _stream()), "ghf_group_outer")
     return out
+
+
+_RANGES: dict = {}
+
+
+def _row_ranges(K: int, step: int, device) -> torch.Tensor:
+    """[0, step, 2 step, ..., K] on the device (cached: a handful of distinct sizes per model)."""
+    key = (K, step, str(device))
+    r = _RANGES.get(key)
+    if r is None:
+        n = (K + step - 1) // step
+        r = torch.tensor([min(i * step, K) for i in range(n + 1)], dtype=torch.int64).to(device)
+        if len(_RANGES) >= 64:
+            _RANGES.pop(next(iter(_RANGES)))
+        _RANGES[key] = r
+    return r
+
+
+def matmul_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """A^T B for row-major A [K, M], B [K, N] -> [M, N] in exact fp32: ghf_group_outer over slices of the K rows (so that
+    a tall contraction fills the chip), the slices' partial products summed in order by ghf_colsum."""
+    K, M = A.shape
+    N = B.size(1)
+    tiles = ((M + 15) // 16) * ((N + 127) // 128)
+    step = K if K <= 512 else max(256, ((K * tiles + 2047) // 2048 + 3) & ~3)      # aim at ~2000 workgroups
+    goff = _row_ranges(K, step, A.device)
+    part = group_outer(A, None, B, None, goff)
+    if part.size(0) == 1:
+        return part[0]
+    return colsum(part.view(part.size(0), M * N)).view(M, N)
+
+
+def matmul_nn(X: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """X W for row-major X [M, K], W [K, N] (the gradient of a Linear with respect to its input)."""
+    return matmul_tn(transpose_batched(X.unsqueeze(0))[0], W)
+
+
+def scale_exp(X: torch.Tensor, log_scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    X = _req(X, torch.float32, "X")
+    out = torch.empty_like(X) if out is None else out
+    _check(load().ghf_scale_exp(_ptr(X), X.numel(), _ptr(_req(log_scale, torch.float32, "log_scale")), _ptr(out), _stream()),
+           "ghf_scale_exp")
+    return out
+
+
+def add3(a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    a, b = _req(a, torch.float32, "a"), _req(b, torch.float32, "b")
+    c = None if c is None else _req(c, torch.float32, "c")
+    if a.numel() != b.numel() or (c is not None and c.numel() != a.numel()):
+        raise ValueError("add3: operands differ in size")
+    out = torch.empty_like(a) if out is None else out
+    _check(load().ghf_add3(_ptr(a), _ptr(b), _ptr(c), a.numel(), _ptr(out), _stream()), "ghf_add3")
+    return out
+
+
+def rowscale(X: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    X, g = _req(X, torch.float32, "X"), _req(g, torch.float32, "g")
+    n, d = X.shape
+    if g.numel() != n:
+        raise ValueError("rowscale: one factor per row expected")
+    out = torch.empty_like(X)
+    _check(load().ghf_rowscale(_ptr(X), _ptr(g), n, d, _ptr(out), _stream()), "ghf_rowscale")
+    return out
+
+
+def dot(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """[1] tensor: sum of the elementwise product (fixed summation order)."""
+    X, Y = _req(X, torch.float32, "X"), _req(Y, torch.float32, "Y")
+    n = X.numel()
+    if Y.numel() != n:
+        raise ValueError("dot: operands differ in size")
+    ws = torch.empty((n + 65535) // 65536, dtype=torch.float32, device=X.device)
+    out = torch.empty(1, dtype=torch.float32, device=X.device)
+    _check(load().ghf_dot(_ptr(X), _ptr(Y), n, _ptr(ws), _ptr(out), _stream()), "ghf_dot")
+    return out
+
+
+def weightgen_acts(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], T: int, Hh: int, num_hidden: int) -> torch.Tensor:
+    """[3, num_hidden, R, Hh]: the post-ReLU hidden activations of the three generator heads."""
+    x = _req(text_emb, torch.float32, "text_emb")
+    keep = [_req(p, torch.float32, "weight-generator parameter") for p in head_params]
+    arr = (_vp * len(keep))(*[p.data_ptr() for p in keep])
+    acts = torch.empty(3, num_hidden, x.size(0), Hh, dtype=torch.float32, device=x.device)
+    _check(load().ghf_weightgen_acts(_ptr(x), arr, x.size(0), T, Hh, num_hidden, _ptr(acts), _stream()), "ghf_weightgen_acts")
+    return acts
+
+
+def text_encode_bwd(ids: torch.Tensor, lens: torch.Tensor, char_emb: torch.Tensor, W: torch.Tensor, te: torch.Tensor,
+                    dte: torch.Tensor):
+    """(d char_emb [V, C], d W [T, C], d b [T]) of ghf_text_encode_fwd."""
+    E, Wt = _req(char_emb, torch.float32, "char_emb.weight"), _req(W, torch.float32, "proj.weight")
+    te, dte = _req(te, torch.float32, "te"), _req(dte, torch.float32, "dte")
+    U, Lmax = ids.shape
+    V, Cd = E.shape
+    T = Wt.size(0)
+    ws = torch.empty(2 * U * Cd + U * T, dtype=torch.float32, device=E.device)
+    dE, dW, db = torch.empty_like(E), torch.empty_like(Wt), torch.empty(T, dtype=torch.float32, device=E.device)
+    _check(load().ghf_text_encode_bwd(_ptr(_req(ids, torch.int32, "ids")), _ptr(_req(lens, torch.int32, "lens")), U, Lmax,
+                                      _ptr(E), V, Cd, _ptr(Wt), T, _ptr(te), _ptr(dte), _ptr(ws), _ptr(dE), _ptr(dW), _ptr(db),
+                                      _stream()), "ghf_text_encode_bwd")
+    return dE, dW, db
 
 
 def transpose_batched(x: torch.Tensor) -> torch.Tensor:

@@ -16,12 +16,17 @@ and ``g' = dL/dh'``:
 
 First version: exact fp32 contractions for the weight gradients, the message kernel for the h gradients; the
 training forward runs the message kernel with GHF_FLAG_NO_TAIL plus ``ghf_tail_fwd`` so that ``out`` can be saved.
+
+The callers either side of the layer have their own Functions here: ``WeightGeneratorFn`` (three MLP heads and the
+learnable log-scales, reference weight_generator.py:120-143), ``InputProjFn`` (hypergnn.py:261), ``TextEncoderFn``
+(hypergnn.py:57-81) and ``ScorePairsFn`` (hypergnn.py:304-318).  All of their contractions are ``A^T B`` over rows,
+i.e. ``ghf_group_outer`` again (``_native.matmul_tn``).
 """
 
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -40,6 +45,8 @@ class TrainPlan:
 
 
 def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: GraphPlan, d: int, device) -> TrainPlan:
+    if fwd.row_lo != 0 or (fwd.row_hi or fwd.N) != fwd.N or fwd.E != edge_index.size(1):
+        raise NotImplementedError("training runs on single-GPU plans (every destination row, every edge)")
     ei = edge_index.to(device=device, dtype=torch.int64)
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     rev = build_plan(ei.flip(0).contiguous(), rel, fwd.unique_texts, fwd.N, d, device)
@@ -62,8 +69,9 @@ def _layer_weights(plan: GraphPlan, Wm: Optional[torch.Tensor], Ws: Optional[tor
                 return z
             return _native.transpose_batched(w) if transpose else w.contiguous()
         return nat(Wm), nat(Ws)
-    if plan.wlayout != _native.WLAYOUT_SPLIT2H:
-        raise NotImplementedError(f"training needs the generic or the SPLIT2H message kernel (plan layout {plan.wlayout})")
+    if plan.wlayout not in (_native.WLAYOUT_SPLIT2H, _native.WLAYOUT_FRAG16):
+        raise NotImplementedError(f"training needs the generic, the FRAG16 or the SPLIT2H message kernel (plan layout "
+                                  f"{plan.wlayout}; unset GHF_KERNEL)")
     return _native.weights_pack(Wm, Ws, transpose, R, d, plan.wlayout), None
 
 
@@ -108,5 +116,112 @@ class MessageLayerFn(torch.autograd.Function):
             zero_b = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)
             Wf, Wf2 = _layer_weights(plan, None, W_self.detach(), transpose=True)       # self term: rows keyed by destination
             Wr, Wr2 = _layer_weights(tp.rev, W_msg.detach(), None, transpose=True)      # message term: scattered to the sources
-            dh = dpre + _raw_message(G, plan, Wf, Wf2, zero_b) + _raw_message(G, tp.rev, Wr, Wr2, zero_b)
+            dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b), _raw_message(G, tp.rev, Wr, Wr2, zero_b), out=dpre)
         return dh, dWm, dWs, db, dgamma, dbeta, None, None
+
+
+class WeightGeneratorFn(torch.autograd.Function):
+    """(W_msg [R,d_in,d_out], W_self [R,d_in,d_out], bias [R,d_out]) = exp(log_scale_k) * MLP_k(text_emb), k = three heads.
+
+    Arguments after the dims: text_emb [R,T], the three log-scales ([1] each), then the flat parameter list
+    [head][layer][weight, bias] exactly as ghf_weightgen_fwd takes it."""
+
+    @staticmethod
+    def forward(ctx, dims, x, ls0, ls1, ls2, *params):
+        T, Hh, nh, d_in, d_out = dims
+        x = x.contiguous().float()
+        flat = [p.detach() for p in params]
+        ls = torch.cat([ls0.detach().reshape(1), ls1.detach().reshape(1), ls2.detach().reshape(1)])
+        outs = _native.weightgen_fwd(x, flat, ls, T, Hh, nh, d_in, d_out, _native.WLAYOUT_NATURAL)
+        acts = _native.weightgen_acts(x, flat, T, Hh, nh) if nh > 0 else None
+        ctx.dims, ctx.acts, ctx.n_params = dims, acts, len(params)
+        ctx.save_for_backward(x, ls, *outs, *params)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        T, Hh, nh, d_in, d_out = ctx.dims
+        x, ls = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        outs, params = ctx.saved_tensors[2:5], ctx.saved_tensors[5:]
+        R, nl = x.size(0), nh + 1
+        dls: List[Optional[torch.Tensor]] = []
+        dparams: List[Optional[torch.Tensor]] = [None] * len(params)
+        dxs: List[torch.Tensor] = []
+        for k in range(3):
+            if grads[k] is None:
+                dls.append(None)
+                continue
+            g = grads[k].contiguous().float().view(R, -1)
+            dls.append(_native.dot(g, outs[k]))                        # out = y exp(ls): d out / d ls = out
+            dy = _native.scale_exp(g, ls[k:k + 1])
+            for l in range(nl - 1, -1, -1):
+                W = params[(k * nl + l) * 2].detach()
+                a_prev = ctx.acts[k, l - 1] if l > 0 else x
+                if l < nl - 1:
+                    dy = _native.relu_mask(dy, ctx.acts[k, l])
+                dparams[(k * nl + l) * 2] = _native.matmul_tn(dy, a_prev)
+                dparams[(k * nl + l) * 2 + 1] = _native.colsum(dy)
+                if l > 0 or ctx.needs_input_grad[1]:
+                    dy = _native.matmul_nn(dy, W)
+            dxs.append(dy)
+        dx = None
+        if ctx.needs_input_grad[1] and dxs:
+            dx = dxs[0] if len(dxs) == 1 else _native.add3(dxs[0], dxs[1], dxs[2] if len(dxs) > 2 else None)
+        return (None, dx, *dls, *dparams)
+
+
+class InputProjFn(torch.autograd.Function):
+    """h0 = relu(x W^T + b) (reference hypergnn.py:261)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous().float()
+        h0 = _native.input_proj_fwd(x, W.detach(), b.detach())
+        ctx.save_for_backward(x, W, h0)
+        return h0
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, h0 = ctx.saved_tensors
+        dz = _native.relu_mask(g.contiguous().float(), h0)
+        dW = _native.matmul_tn(dz, x)
+        db = _native.colsum(dz)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x.size(0) > 16 * 65535:
+                raise NotImplementedError("gradient with respect to node_features: at most 1,048,560 rows for now")
+            dx = _native.matmul_nn(dz, W.detach().contiguous())
+        return dx, dW, db
+
+
+class TextEncoderFn(torch.autograd.Function):
+    """te = tanh(mean_l E[ids] W^T + b) for all strings at once (reference hypergnn.py:57-81)."""
+
+    @staticmethod
+    def forward(ctx, E, W, b, ids, lens):
+        te = _native.text_encode_fwd(ids, lens, E.detach(), W.detach(), b.detach())
+        ctx.save_for_backward(E, W, te, ids, lens)
+        return te
+
+    @staticmethod
+    def backward(ctx, g):
+        E, W, te, ids, lens = ctx.saved_tensors
+        dE, dW, db = _native.text_encode_bwd(ids, lens, E.detach(), W.detach(), te, g.contiguous().float())
+        return dE, dW, db, None, None
+
+
+class ScorePairsFn(torch.autograd.Function):
+    """s_i = a_i . b_i (reference score_triple, hypergnn.py:304-318)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous().float(), b.contiguous().float()
+        ctx.save_for_backward(a, b)
+        return _native.score_pairs_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        return (_native.rowscale(b, g) if ctx.needs_input_grad[0] else None,
+                _native.rowscale(a, g) if ctx.needs_input_grad[1] else None)

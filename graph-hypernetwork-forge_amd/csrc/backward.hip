@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
     if (i < n) out[i] = ref[i] > 0.f ? X[i] : 0.f;
 }
 
-// C[g][i][o] (+)= sum_{e in group g} A[ia[e]][i] * B[ib[e]][o],  groups = contiguous ranges goff[g] .. goff[g+1] of e.
+// C[g][i][o] (+)= sum_{e in group g} A[ia[e]][i] * B[ib[e]][o],  group g = the range gstart[g] .. gend[g] of e.
 // One workgroup per (group, 16-row tile of i): its 4 waves take contiguous quarters of the group's edges, every wave
 // runs v_mfma_f32_16x16x4_f32 over 4 edges per step (A fragment: lane (i = l&15, k = l>>4) = A[ia[e+k]][i0+i];
 // B fragment: B[ib[e+k]][16t + (l&15)]), and the four partial tiles are added in wave order through LDS: the
@@ -113,13 +113,13 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
 template <int NTB>   // 16-column tiles of B handled per pass (db <= 16*NTB per pass)
 __global__ __launch_bounds__(256) void group_outer_kernel(const float* __restrict__ A, const int64_t* __restrict__ ia, int da,
                                                           const float* __restrict__ B, const int64_t* __restrict__ ib, int db,
-                                                          const int64_t* __restrict__ goff, float* __restrict__ Cout,
-                                                          int o_base, int accumulate) {
+                                                          const int64_t* __restrict__ gstart, const int64_t* __restrict__ gend,
+                                                          float* __restrict__ Cout, int o_base, int accumulate) {
     __shared__ float red[4][16][16 * NTB + 1];
     const int g = blockIdx.x, it = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int64_t e0 = goff[g], e1 = goff[g + 1];
+    const int64_t e0 = gstart[g], e1 = gend[g];
     const int64_t per = ((e1 - e0 + 3) / 4 + 3) & ~(int64_t)3;            // edges per wave, a multiple of 4
     const int64_t w0 = e0 + w * per, w1 = (w0 + per < e1) ? w0 + per : e1;
     const int i = it * 16 + c16;
@@ -204,14 +204,80 @@ int launch_relu_mask(const float* X, const float* ref, int64_t n, float* out, hi
 }
 
 int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
-                       const int64_t* goff, int ngroups, float* C, int accumulate, hipStream_t stream) {
+                       const int64_t* gstart, const int64_t* gend, int ngroups, float* C, int accumulate, hipStream_t stream) {
     GHF_REQUIRE(da >= 0 && db > 0 && ngroups > 0, "group_outer: bad shape");
     const int rows_a = da > 0 ? da : 1;
     const dim3 grid((unsigned)ngroups, (unsigned)cdiv(rows_a, 16));
     for (int o_base = 0; o_base < db; o_base += 128) {
-        group_outer_kernel<8><<<grid, 256, 0, stream>>>(A, ia, da, B, ib, db, goff, C, o_base, accumulate);
+        group_outer_kernel<8><<<grid, 256, 0, stream>>>(A, ia, da, B, ib, db, gstart, gend, C, o_base, accumulate);
         GHF_LAUNCH_CHECK();
     }
+    return GHF_OK;
+}
+
+// out[0] = sum_i X[i] * Y[i], two deterministic stages (workspace: cdiv(n, 65536) floats)
+__global__ __launch_bounds__(256) void dot_stage1_kernel(const float* __restrict__ X, const float* __restrict__ Y, int64_t n,
+                                                         float* __restrict__ part) {
+    __shared__ float red[4];
+    const int64_t b0 = (int64_t)blockIdx.x * 65536;
+    float s = 0.f;
+    for (int64_t i = b0 + threadIdx.x; i < b0 + 65536 && i < n; i += 256) s = fmaf(X[i], Y[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ void dot_stage2_kernel(const float* __restrict__ part, int64_t nblk, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int64_t b = 0; b < nblk; ++b) s += part[b];
+        out[0] = s;
+    }
+}
+
+int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream) {
+    GHF_REQUIRE(n > 0, "dot: empty input");
+    const int64_t nblk = cdiv(n, 65536);
+    dot_stage1_kernel<<<(unsigned)nblk, 256, 0, stream>>>(X, Y, n, workspace);
+    GHF_LAUNCH_CHECK();
+    dot_stage2_kernel<<<1, 64, 0, stream>>>(workspace, nblk, out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+// elementwise helpers of the backward (HBM-bound, 16 bytes per lane where the length allows)
+__global__ __launch_bounds__(256) void scale_exp_kernel(const float* __restrict__ X, int64_t n, const float* __restrict__ log_scale,
+                                                        float* __restrict__ out) {
+    const float s = expf(log_scale[0]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = X[i] * s;
+}
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ c, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = c ? (a[i] + b[i]) + c[i] : a[i] + b[i];
+}
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ X, const float* __restrict__ g, int64_t n, int d,
+                                                       float* __restrict__ out) {
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] = X[i] * g[i / d];
+}
+
+static unsigned ew_grid(int64_t n) { const int64_t b = cdiv(n, 256); return (unsigned)(b < 8192 ? (b > 0 ? b : 1) : 8192); }
+
+int launch_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, hipStream_t stream) {
+    scale_exp_kernel<<<ew_grid(n), 256, 0, stream>>>(X, n, log_scale, out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+int launch_add3(const float* a, const float* b, const float* c, int64_t n, float* out, hipStream_t stream) {
+    add3_kernel<<<ew_grid(n), 256, 0, stream>>>(a, b, c, n, out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+int launch_rowscale(const float* X, const float* g, int64_t n, int d, float* out, hipStream_t stream) {
+    GHF_REQUIRE(d > 0, "rowscale: d must be positive");
+    rowscale_kernel<<<ew_grid(n * d), 256, 0, stream>>>(X, g, n, d, out);
+    GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
 

@@ -141,8 +141,6 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
                 "message_layer_fwd: null pointer argument");
     if (flags & GHF_FLAG_RAW_SUM) flags |= GHF_FLAG_NO_TAIL;
     GHF_REQUIRE((flags & GHF_FLAG_NO_TAIL) || (ln_gamma && ln_beta), "message_layer_fwd: LayerNorm parameters missing");
-    GHF_REQUIRE(!(flags & GHF_FLAG_RAW_SUM) || block_nodes == 1 || wlayout == GHF_WLAYOUT_SPLIT2H,
-                "message_layer_fwd: GHF_FLAG_RAW_SUM is implemented by the generic and the SPLIT2H kernels");
     GHF_REQUIRE(h != h_out, "message_layer_fwd: h_out must not alias h");
     GHF_REQUIRE(N > 0 && d > 0 && R > 0 && block_nodes > 0, "message_layer_fwd: N, d, R, block_nodes must be positive");
     GHF_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= N, "message_layer_fwd: row range [%lld,+%lld) outside [0,%lld)",
@@ -190,9 +188,43 @@ int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void*
 }
 
 int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
-                    const int64_t* goff, int ngroups, float* C, int accumulate, void* stream) {
-    GHF_REQUIRE((A || da == 0) && B && goff && C, "group_outer: null pointer argument");
-    return launch_group_outer(A, ia, da, B, ib, db, goff, ngroups, C, accumulate, (hipStream_t)stream);
+                    const int64_t* gstart, const int64_t* gend, int ngroups, float* C, int accumulate, void* stream) {
+    GHF_REQUIRE((A || da == 0) && B && gstart && gend && C, "group_outer: null pointer argument");
+    return launch_group_outer(A, ia, da, B, ib, db, gstart, gend, ngroups, C, accumulate, (hipStream_t)stream);
+}
+
+int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream) {
+    GHF_REQUIRE((X && log_scale && out) || n == 0, "scale_exp: null pointer argument");
+    return n > 0 ? launch_scale_exp(X, n, log_scale, out, (hipStream_t)stream) : GHF_OK;
+}
+
+int ghf_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream) {
+    GHF_REQUIRE((a && b && out) || n == 0, "add3: null pointer argument");
+    return n > 0 ? launch_add3(a, b, c, n, out, (hipStream_t)stream) : GHF_OK;
+}
+
+int ghf_rowscale(const float* X, const float* g, int64_t n, int d, float* out, void* stream) {
+    GHF_REQUIRE((X && g && out) || n == 0, "rowscale: null pointer argument");
+    return n > 0 ? launch_rowscale(X, g, n, d, out, (hipStream_t)stream) : GHF_OK;
+}
+
+int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, void* stream) {
+    GHF_REQUIRE(X && Y && workspace && out, "dot: null pointer argument");
+    return launch_dot(X, Y, n, workspace, out, (hipStream_t)stream);
+}
+
+int ghf_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
+                       float* acts, void* stream) {
+    GHF_REQUIRE(text_emb && head_params && (acts || num_hidden == 0), "weightgen_acts: null pointer argument");
+    return launch_weightgen_acts(text_emb, head_params, R, T, Hh, num_hidden, acts, (hipStream_t)stream);
+}
+
+int ghf_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
+                        const float* W, int T, const float* te, const float* dte, float* workspace, float* d_char_emb,
+                        float* dW, float* db, void* stream) {
+    GHF_REQUIRE(ids && lens && char_emb && W && te && dte && workspace && d_char_emb && dW && db, "text_encode_bwd: null pointer argument");
+    return launch_text_encode_bwd(ids, lens, U, Lmax, char_emb, V, C, W, T, te, dte, workspace, d_char_emb, dW, db,
+                                  (hipStream_t)stream);
 }
 
 int ghf_transpose_batched(const float* in, int batch, int rows, int cols, float* out, void* stream) {

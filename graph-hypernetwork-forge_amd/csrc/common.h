@@ -158,7 +158,16 @@ size_t colsum_workspace_floats(int64_t N, int d);
 int launch_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, hipStream_t stream);
 int launch_relu_mask(const float* X, const float* ref, int64_t n, float* out, hipStream_t stream);
 int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
-                       const int64_t* goff, int ngroups, float* C, int accumulate, hipStream_t stream);
+                       const int64_t* gstart, const int64_t* gend, int ngroups, float* C, int accumulate, hipStream_t stream);
+int launch_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, hipStream_t stream);
+int launch_add3(const float* a, const float* b, const float* c, int64_t n, float* out, hipStream_t stream);
+int launch_rowscale(const float* X, const float* g, int64_t n, int d, float* out, hipStream_t stream);
+int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream);
+int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
+                          float* acts, hipStream_t stream);
+int launch_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* E, int V, int C, const float* W,
+                           int T, const float* te, const float* dte, float* workspace, float* dE, float* dW, float* db,
+                           hipStream_t stream);
 int launch_transpose_batched(const float* in, int batch, int rows, int cols, float* out, hipStream_t stream);
 int launch_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int layout, float* out,
                         hipStream_t stream);

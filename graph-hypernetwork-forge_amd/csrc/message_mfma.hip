@@ -379,7 +379,7 @@ __global__ __launch_bounds__(MfmaCfg<D>::NW * 64) void message_mfma_kernel(
             const int vc = v < nrows ? v : v0;                          // clamp: surplus rows recompute row v0, not stored
             const int64_t node = node0 + vc;
             const int deg = indeg[node];
-            inv[rb] = 1.0f / (float)(deg > 1 ? deg : 1);
+            inv[rb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + lane * CPL + c];
         }
@@ -432,7 +432,7 @@ static int launch_for(const MsgArgs& a, hipStream_t stream) {
     static const int dbg = getenv("GHF_DEBUG_FLAGS") ? atoi(getenv("GHF_DEBUG_FLAGS")) : 0;   // diagnostic ablations, see DESIGN.md
     message_mfma_kernel<D><<<grid, C::NW * 64, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.blk_chunk_off,
                                                               a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma, a.ln_beta, a.ln_eps,
-                                                              a.row0, row_end, a.h_out, (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0, dbg);
+                                                              a.row0, row_end, a.h_out, a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), dbg);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

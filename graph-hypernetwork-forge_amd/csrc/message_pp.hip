@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
             const int vc = v < nrows ? v : v0;
             const int64_t node = node0 + vc;
             const int deg = indeg[node];
-            inv[rb] = 1.0f / (float)(deg > 1 ? deg : 1);
+            inv[rb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + col[c]];
         }
@@ -501,7 +501,7 @@ static int launch_pp_for(const MsgArgs& a, hipStream_t stream) {
     message_pp_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
                                                                    a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
                                                                    a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out,
-                                                                   (a.flags & GHF_FLAG_NO_TAIL) ? 1 : 0);
+                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
     GHF_LAUNCH_CHECK();
     if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
     return GHF_OK;

@@ -27,9 +27,10 @@ struct HeadPtrs {
 };
 
 // grid (R, 3); block 256.  hidden_ws[(head*R + r)*Hl + j], Hl = num_hidden ? Hh : T.
+// acts (optional): every hidden layer's output, acts[((head*num_hidden + layer)*R + r)*Hh + j]  (the backward's input)
 __global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict__ text_emb, HeadPtrs P,
                                                         int R, int T, int Hh, int num_hidden,
-                                                        float* __restrict__ hidden_ws) {
+                                                        float* __restrict__ hidden_ws, float* __restrict__ acts) {
     __shared__ float buf[2][WG_MAX_WIDTH];
     const int r = blockIdx.x, head = blockIdx.y;
     for (int k = threadIdx.x; k < T; k += blockDim.x) buf[0][k] = text_emb[(size_t)r * T + k];
@@ -60,7 +61,12 @@ __global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict_
         __syncthreads();
         cur ^= 1;
         in_dim = Hh;
+        if (acts) {
+            float* a = acts + (((size_t)head * num_hidden + li) * R + r) * Hh;
+            for (int k = threadIdx.x; k < Hh; k += blockDim.x) a[k] = buf[cur][k];
+        }
     }
+    if (!hidden_ws) return;
     float* out = hidden_ws + ((size_t)head * R + r) * in_dim;
     for (int k = threadIdx.x; k < in_dim; k += blockDim.x) out[k] = buf[cur][k];
 }
@@ -253,6 +259,23 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
     }
 }
 
+int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
+                          float* acts, hipStream_t stream) {
+    GHF_REQUIRE(R > 0 && T > 0 && num_hidden >= 0 && num_hidden <= 7, "weightgen_acts: bad shape");
+    GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen_acts: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
+    if (num_hidden == 0) return GHF_OK;
+    HeadPtrs P;
+    const int nl = num_hidden + 1;
+    for (int h = 0; h < 3; ++h)
+        for (int l = 0; l < nl; ++l) {
+            P.w[h][l] = head_params[(h * nl + l) * 2 + 0];
+            P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
+        }
+    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, nullptr, acts);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 // ghf_weights_pack: [W_top[r]; W_bottom[r]] (each [d,d] natural, optionally transposed, NULL = zeros) -> the [R][2d][d]
 // fp32 matrix the in-place packer takes.  Used for the backward passes' transposed weights.
 __global__ __launch_bounds__(256) void wg_combine_kernel(const float* __restrict__ top, const float* __restrict__ bottom,
@@ -269,9 +292,30 @@ __global__ __launch_bounds__(256) void wg_combine_kernel(const float* __restrict
     }
 }
 
+// the same stacked matrix straight into FRAG16 order (fp32, one float per weight: no second pass)
+__global__ __launch_bounds__(256) void wg_combine_frag16_kernel(const float* __restrict__ top, const float* __restrict__ bottom,
+                                                                int transpose, int d, float* __restrict__ out) {
+    const int r = blockIdx.y;
+    const int n = 2 * d * d;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int kk = idx / d, o = idx - kk * d;
+        const float* src = kk < d ? top : bottom;
+        const int k = kk < d ? kk : kk - d;
+        float v = 0.f;
+        if (src) v = transpose ? src[((size_t)r * d + o) * d + k] : src[((size_t)r * d + k) * d + o];
+        out[frag16_index(r, kk, o, d)] = v;
+    }
+}
+
 int launch_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int layout, float* out,
                         hipStream_t stream) {
     GHF_REQUIRE(R > 0 && d > 0 && out, "weights_pack: bad arguments");
+    if (layout == GHF_WLAYOUT_FRAG16) {
+        GHF_REQUIRE((d % 16) == 0, "weights_pack: FRAG16 needs d %% 16 == 0");
+        wg_combine_frag16_kernel<<<dim3(32, (unsigned)R), 256, 0, stream>>>(top, bottom, transpose, d, out);
+        GHF_LAUNCH_CHECK();
+        return GHF_OK;
+    }
     GHF_REQUIRE(layout == GHF_WLAYOUT_SPLIT2H, "weights_pack: layout %d is not packed from natural matrices here", layout);
     GHF_REQUIRE((d % 32) == 0 && (size_t)2 * d * d * 4 <= 128 * 1024, "weights_pack: SPLIT2H needs d %% 32 == 0, d <= 128");
     wg_combine_kernel<<<dim3(32, (unsigned)R), 256, 0, stream>>>(top, bottom, transpose, d, out);
@@ -312,7 +356,7 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
             P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
             GHF_REQUIRE(P.w[h][l] && P.b[h][l], "weightgen: null parameter pointer (head %d layer %d)", h, l);
         }
-    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, hidden_ws);
+    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, hidden_ws, nullptr);
     GHF_LAUNCH_CHECK();
 
     const int Hl = num_hidden ? Hh : T;

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from .. import _native
 from ..plan import GraphPlan, PlanCache, build_plan, relation_ids
-from .weight_generator import WeightGenerator, require_inference
+from .weight_generator import WeightGenerator, require_inference, wants_grad
 
 
 class TextEncoder(nn.Module):
@@ -69,9 +69,12 @@ class TextEncoder(nn.Module):
         return hit
 
     def forward(self, texts: Sequence[str], device: torch.device) -> torch.Tensor:
-        require_inference(self, self.char_emb.weight)
+        grad = wants_grad(self, self.char_emb.weight)
         ids, lens = self._token_matrix(texts, torch.device(device))
         lin = self.proj[0]
+        if grad:
+            from ..autograd import TextEncoderFn
+            return TextEncoderFn.apply(self.char_emb.weight, lin.weight, lin.bias, ids, lens)
         return _native.text_encode_fwd(ids, lens, self.char_emb.weight.detach(), lin.weight.detach(), lin.bias.detach())
 
 
@@ -120,7 +123,8 @@ class HyperGNN(nn.Module):
             raise ValueError(f"edge_index has {edge_index.size(1)} edges but edge_rel_ids has {edge_rel_ids.numel()} entries")
         if node_features.dim() != 2 or node_features.size(1) != self.node_feat_dim:
             raise ValueError(f"node_features must be [N, {self.node_feat_dim}], got {tuple(node_features.shape)}")
-        require_inference(self, node_features)
+        grad = wants_grad(self, node_features)
+        self._check_dropout()
         device, N = node_features.device, node_features.size(0)
         texts = list(relation_texts)
         key = ("ids", edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
@@ -130,6 +134,8 @@ class HyperGNN(nn.Module):
         if plan is None:
             plan = build_plan(edge_index, edge_rel_ids, texts, N, self.hidden_dim, device)   # ids out of range: IndexError
             self._plans.put(key, plan, edge_index, (edge_rel_ids, texts))
+        if grad:
+            return self._forward_recorded(node_features, plan, edge_index)
         return self.forward_planned(node_features, plan)
 
     # -- forward (reference :236-298) -----------------------------------------------------
@@ -139,17 +145,38 @@ class HyperGNN(nn.Module):
                              f"edge_texts has {len(edge_texts)} entries")
         if node_features.dim() != 2 or node_features.size(1) != self.node_feat_dim:
             raise ValueError(f"node_features must be [N, {self.node_feat_dim}], got {tuple(node_features.shape)}")
-        require_inference(self, node_features)
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("HyperGNN: dropout in training mode is not implemented on the HIP path")
+        grad = wants_grad(self, node_features)
+        self._check_dropout()
         device = node_features.device
         plan = self.plan_for(edge_index, edge_texts, node_features.size(0), device)
+        if grad:
+            return self._forward_recorded(node_features, plan, edge_index)
         return self.forward_planned(node_features, plan)
+
+    def _check_dropout(self) -> None:
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("HyperGNN: dropout in training mode is not implemented on the HIP path")
+
+    def _forward_recorded(self, node_features: torch.Tensor, plan: GraphPlan, edge_index: torch.Tensor) -> torch.Tensor:
+        """The forward when gradients are required (reference: plain autograd, demo.py:79-101): the same kernels inside
+        ``autograd`` Functions whose backward is C-ABI calls too.  The reversed-graph plan and the relation grouping the
+        backward needs are built once per plan."""
+        from ..autograd import InputProjFn, MessageLayerFn, build_train_plan
+        device = node_features.device
+        if plan.train is None:
+            plan.train = build_train_plan(edge_index, plan.rel_ids, plan, self.hidden_dim, device)
+        text_embs = self.text_encoder(plan.unique_texts, device)
+        h = InputProjFn.apply(node_features, self.input_proj.weight, self.input_proj.bias)
+        for gen, norm in zip(self.weight_generators, self.layer_norms):
+            W_msg, W_self, bias = gen.generate_with_grad(text_embs)
+            h = MessageLayerFn.apply(h, W_msg, W_self, bias, norm.weight, norm.bias, norm.eps, plan.train)
+        return h
 
     def forward_planned(self, node_features: torch.Tensor, plan: GraphPlan,
                         exchange=None) -> torch.Tensor:
         """Forward with an explicit plan.  `exchange(h)` (multi-GPU) runs after every layer to
         make all rows of h visible on this rank; the plan's row range says which rows it computes."""
+        require_inference(self, node_features, what=".forward_planned")
         device = node_features.device
         x = node_features if node_features.dtype == torch.float32 else node_features.float()
         text_embs = self.text_encoder(plan.unique_texts, device)     # [U, text_dim]
@@ -183,7 +210,7 @@ class HyperGNN(nn.Module):
 
         Every edge is treated as its own relation on the generic kernel (no residual/norm);
         needs N*E < 2^32, which per-edge [E,d,d] inputs never approach."""
-        require_inference(self, h)
+        require_inference(self, h, what="._message_passing")
         N, E = h.size(0), edge_index.size(1)
         rel = torch.arange(E, dtype=torch.int64, device=h.device)
         plan = build_plan(edge_index, rel, [""] * E, N, h.size(1), h.device, force_generic=True)
@@ -195,19 +222,28 @@ class HyperGNN(nn.Module):
     # -- convenience (reference :304-322) ---------------------------------------------------
     def score_triple(self, head_emb: torch.Tensor, tail_emb: torch.Tensor) -> torch.Tensor:
         """Dot-product score of (head, tail) embeddings, ``[d]`` or ``[B, d]`` (reference :304-318)."""
-        require_inference(self, head_emb, tail_emb)
+        for t in (head_emb, tail_emb):
+            if not t.is_cuda:
+                raise RuntimeError(f"score_triple computes on an MI355X HIP device only (input is on {t.device})")
         if head_emb.shape != tail_emb.shape or head_emb.dim() not in (1, 2):
             raise ValueError(f"score_triple: shapes {tuple(head_emb.shape)} and {tuple(tail_emb.shape)}")
         single = head_emb.dim() == 1
         a = (head_emb.unsqueeze(0) if single else head_emb).float()
         b = (tail_emb.unsqueeze(0) if single else tail_emb).float()
-        s = _native.score_pairs_fwd(a, b)
+        if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+            from ..autograd import ScorePairsFn
+            s = ScorePairsFn.apply(a, b)
+        else:
+            s = _native.score_pairs_fwd(a, b)
         return s[0] if single else s
 
     def score_edges(self, embs: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
         """``score_triple(embs[src], embs[dst])`` (the reference's call form, demo.py:90-94) without materialising the
         two gathered ``[E, d]`` matrices."""
-        require_inference(self, embs)
+        if not embs.is_cuda:
+            raise RuntimeError(f"score_edges computes on an MI355X HIP device only (input is on {embs.device})")
+        if torch.is_grad_enabled() and embs.requires_grad:
+            raise NotImplementedError("score_edges has no backward; use score_triple(embs[src], embs[dst]) when training")
         return _native.score_pairs_fwd(embs, embs, src.to(torch.int64), dst.to(torch.int64))
 
     def num_parameters(self) -> int:

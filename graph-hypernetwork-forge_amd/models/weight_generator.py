@@ -5,7 +5,9 @@ Same constructor, attributes, ``state_dict`` keys and output dict as
 reference; ``forward`` runs the relation-batched HIP kernels of
 ``csrc/weightgen.hip`` through the C ABI (``ghf_weightgen_fwd``) instead of
 three ``nn.Sequential`` stacks.  The ``nn.Linear`` modules exist to hold the
-parameters under the reference's names; they are never called.
+parameters under the reference's names; they are never called.  When gradients
+are required the same kernels run inside ``autograd.WeightGeneratorFn``, whose
+backward is C-ABI calls as well.
 """
 
 from __future__ import annotations
@@ -21,18 +23,23 @@ from .. import _native
 HEADS: Tuple[str, ...] = ("W_msg", "W_self", "bias")     # reference weight_generator.py:72-76
 
 
-def require_inference(module: nn.Module, *tensors: torch.Tensor) -> None:
-    """The HIP path is forward-only (SURVEY.md §8f-1 lists backward as the next row)."""
+def wants_grad(module: nn.Module, *tensors: torch.Tensor) -> bool:
+    """Checks that the inputs live on the HIP device; True when autograd has to record this call."""
     for t in tensors:
         if not t.is_cuda:
             raise RuntimeError(
                 f"{type(module).__name__} computes on an MI355X HIP device only (input is on {t.device}); "
                 "this package has no CPU or eager-PyTorch fallback")
-    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
-                                    any(p.requires_grad for p in module.parameters())):
+    return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
+                                        any(p.requires_grad for p in module.parameters()))
+
+
+def require_inference(module: nn.Module, *tensors: torch.Tensor, what: str = "") -> None:
+    """For the few entry points that have no backward on the HIP path."""
+    if wants_grad(module, *tensors):
         raise NotImplementedError(
-            f"{type(module).__name__}: the HIP path implements the inference forward only; call it under "
-            "torch.no_grad() (or after .requires_grad_(False)). Training through it is not implemented yet.")
+            f"{type(module).__name__}{what}: no backward on the HIP path; call it under torch.no_grad() "
+            "(or after .requires_grad_(False)).")
 
 
 class WeightGenerator(nn.Module):
@@ -83,6 +90,15 @@ class WeightGenerator(nn.Module):
                 flat += [lin.weight.detach(), lin.bias.detach()]
         return flat
 
+    def _head_parameters(self) -> List[torch.Tensor]:
+        return [p for head in HEADS for lin in self._linears(head) for p in (lin.weight, lin.bias)]
+
+    def generate_with_grad(self, text_emb: torch.Tensor):
+        """Natural-layout (W_msg, W_self, bias) recorded by autograd (backward through the C ABI)."""
+        from ..autograd import WeightGeneratorFn
+        dims = (self.text_dim, self.hidden_dim, self.num_hidden, self.d_in, self.d_out)
+        return WeightGeneratorFn.apply(dims, text_emb, *(self.log_scales[h] for h in HEADS), *self._head_parameters())
+
     def _log_scale_vector(self) -> torch.Tensor:
         return torch.cat([self.log_scales[h].detach().reshape(1) for h in HEADS])
 
@@ -96,10 +112,10 @@ class WeightGenerator(nn.Module):
         single = text_emb.dim() == 1
         if text_emb.size(-1) != self.text_dim:
             raise ValueError(f"text_emb has last dim {text_emb.size(-1)}, expected text_dim={self.text_dim}")
-        require_inference(self, text_emb)
+        grad = wants_grad(self, text_emb)
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("WeightGenerator: dropout in training mode is not implemented on the HIP path")
         x = text_emb.unsqueeze(0) if single else text_emb
-        W_msg, W_self, bias = self.generate(x.float())
+        W_msg, W_self, bias = self.generate_with_grad(x.float()) if grad else self.generate(x.float())
         out = {"W_msg": W_msg, "W_self": W_self, "bias": bias}
         return {k: v.squeeze(0) for k, v in out.items()} if single else out

@@ -53,6 +53,7 @@ class GraphPlan:
     chunk_rows: int = 0
     row_lo: int = 0                # destination rows this plan covers (multi-GPU shards)
     row_hi: int = 0
+    train: Optional[object] = None  # autograd.TrainPlan, built by the first forward that records gradients
 
     def bytes(self) -> int:
         ts = (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg, self.chunk_tab, self.blk_chunk_off,

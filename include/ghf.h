@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 6
+#define GHF_ABI_VERSION 7
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -171,7 +171,7 @@ int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
  * With out_v = (1/c_v) sum_e(h_u Wm[r] + b[r] + h_v Ws[r]), x = relu(out + h), h' = LayerNorm(x), g' = dL/dh':
  *   ghf_tail_bwd   : dpre = dL/d(out+h) (also the residual's share of dL/dh), G_v = dpre_v / c_v, T = g' * xhat
  *                    (dgamma = colsum(T), dbeta = colsum(g'));  agg is the forward's GHF_FLAG_NO_TAIL output
- *   ghf_group_outer: C[g][i][o] (+)= sum_{e in goff[g]..goff[g+1]} A[ia[e]][i] * B[ib[e]][o]; ia / ib NULL = e itself,
+ *   ghf_group_outer: C[g][i][o] (+)= sum_{e in gstart[g]..gend[g]} A[ia[e]][i] * B[ib[e]][o]; ia / ib NULL = e itself,
  *                    da == 0: A = 1 (C is [ngroups][1][db]).  dWm[r] = sum h_u^T G_v, dWs[r], db[r], and the Linear
  *                    layers' weight gradients.  Summation order fixed: reproducible.
  *   ghf_colsum     : out[o] (+)= sum_v X[v][o] * (mask ? mask[v][o] > 0 : 1); workspace: ghf_colsum_workspace_floats
@@ -189,7 +189,24 @@ size_t ghf_colsum_workspace_floats(int64_t N, int d);
 int ghf_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, void* stream);
 int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void* stream);
 int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
-                    const int64_t* goff, int ngroups, float* C, int accumulate, void* stream);
+                    const int64_t* gstart, const int64_t* gend, int ngroups, float* C, int accumulate, void* stream);
+/* Elementwise pieces of the backward: out = X * exp(log_scale[0]) (log_scale on the device: the generator's learnable
+ * scale, reference weight_generator.py:137-141); out = a + b (+ c when non-NULL); out[i][:] = g[i] * X[i][:] (the two
+ * gradients of score_triple, reference hypergnn.py:304-318).  out may alias an input. */
+int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream);
+int ghf_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
+int ghf_rowscale(const float* X, const float* g, int64_t n, int d, float* out, void* stream);
+/* out[0] = sum_i X[i] Y[i] (fixed order); workspace: (n + 65535) / 65536 floats */
+int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, void* stream);
+/* Hidden activations of the weight generator's three heads (what its backward needs besides the outputs):
+ * acts[head][layer][r][Hh], layer = 0 .. num_hidden-1 (post-ReLU).  Same head_params as ghf_weightgen_fwd. */
+int ghf_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
+                       float* acts, void* stream);
+/* Backward of ghf_text_encode_fwd: given te = its output and dte = dL/dte, writes dL/dchar_emb [V,C], dL/dW [T,C],
+ * dL/db [T] (overwritten, fixed summation order).  workspace: 2*U*C + U*T floats. */
+int ghf_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
+                        const float* W, int T, const float* te, const float* dte, float* workspace,
+                        float* d_char_emb, float* dW, float* db, void* stream);
 int ghf_transpose_batched(const float* in, int batch, int rows, int cols, float* out, void* stream);
 int ghf_weights_pack(const float* top, const float* bottom, int transpose, int R, int d, int wlayout, float* out, void* stream);
 

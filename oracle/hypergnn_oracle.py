@@ -34,8 +34,8 @@ LN_EPS = 1e-5       # nn.LayerNorm default, reference hypergnn.py:152-154
 
 
 def _t(x, dtype: torch.dtype) -> torch.Tensor:
-    if isinstance(x, torch.Tensor):
-        return x.detach().to("cpu", dtype)
+    if isinstance(x, torch.Tensor):                        # leaves that require grad stay attached: the backward tests
+        return (x if x.requires_grad else x.detach()).to("cpu", dtype)   # differentiate this restatement with autograd
     return torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
 
 

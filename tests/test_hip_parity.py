@@ -503,6 +503,123 @@ def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind)
         assert rel_l2 < 2e-5, f"d{name}: relative L2 {rel_l2:.3e}"
 
 
+def _grad_check(name, got, want, rtol=2e-4, l2=5e-5):
+    gw, gg = want.astype(np.float64), got.astype(np.float64)
+    assert gg.shape == gw.shape, f"d{name}: shape {gg.shape} vs {gw.shape}"
+    scale = float(np.abs(gw).max())
+    assert np.allclose(gg, gw, rtol=rtol, atol=1e-4 * max(scale, 1e-30)), \
+        f"d{name}: max abs err {np.abs(gg - gw).max():.3e} at scale {scale:.3e}"
+    rel_l2 = np.linalg.norm(gg - gw) / max(np.linalg.norm(gw), 1e-30)
+    assert rel_l2 < l2, f"d{name}: relative L2 {rel_l2:.3e}"
+
+
+@pytest.mark.parametrize("T,Hh,nh,d_in,d_out,R", [(32, 64, 2, 16, 16, 7), (64, 128, 2, 128, 128, 5), (16, 40, 1, 8, 24, 3),
+                                                  (16, 32, 0, 8, 8, 4), (32, 64, 3, 20, 20, 1)])
+def test_weight_generator_backward_matches_autograd_of_the_oracle(T, Hh, nh, d_in, d_out, R):
+    """Reference tests/test_weight_generator.py:86-106 (gradient reaches the embedding, the scales train) made exact: every
+    gradient of WeightGenerator.forward against torch.autograd through the oracle, in float64."""
+    torch.manual_seed(T + Hh + nh)
+    gen = WeightGenerator(T, d_in, d_out, hidden_dim=Hh, num_hidden=nh).to(DEV)
+    with torch.no_grad():
+        for h in ("W_msg", "W_self", "bias"):
+            gen.generators[h][-1].weight.mul_(30.0)                    # beyond the 0.01 initialisation
+            gen.generators[h][-1].bias.normal_(0.0, 0.3)
+            gen.log_scales[h].fill_({"W_msg": -0.5, "W_self": 0.25, "bias": -1.0}[h])
+    x = torch.from_numpy(synth.normal(5, "wgx", (R, T))).to(DEV).requires_grad_(True)
+    out = gen(x)
+    gouts = {k: torch.from_numpy(synth.normal(6, "g" + k, tuple(v.shape))) for k, v in out.items()}
+    sum((out[k] * gouts[k].to(DEV)).sum() for k in out).backward()
+    ref_p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in gen.state_dict(keep_vars=True).items()}
+    xr = x.detach().cpu().double().requires_grad_(True)
+    ref = O.weight_generator(ref_p, "", xr, d_in, d_out, dtype=torch.float64)
+    for k in out:
+        assert_close(out[k].detach().cpu().numpy(), ref[k].detach().float().numpy(), f"training forward {k}")
+    sum((ref[k] * gouts[k].double()).sum() for k in ref).backward()
+    _grad_check("text_emb", x.grad.cpu().numpy(), xr.grad.numpy())
+    for k, p in gen.named_parameters():
+        assert p.grad is not None, f"no gradient on {k}"
+        _grad_check(k, p.grad.cpu().numpy(), ref_p[k].grad.numpy())
+    single = gen(x.detach()[0].clone().requires_grad_(True))            # 1-D embedding (reference :132-134)
+    assert single["W_msg"].shape == (d_in, d_out) and single["W_msg"].requires_grad
+
+
+def _model_grads(name, node_features, edge_index, edge_texts, gout, x_grad=False):
+    """(HIP model with .grad filled, oracle float64 parameters with .grad filled, outputs) for loss = sum(out * gout)."""
+    cfg = cases.MODELS[name]
+    params = cfg.params()
+    model = make_model(cfg, params).train()
+    x = torch.from_numpy(node_features).to(DEV).requires_grad_(x_grad)
+    out = model(x, torch.from_numpy(edge_index).to(DEV), edge_texts)
+    (out * torch.from_numpy(gout).to(DEV)).sum().backward()
+    ref_p = {k: torch.from_numpy(np.ascontiguousarray(v)).double().requires_grad_(True) for k, v in params.items()}
+    xr = torch.from_numpy(node_features).double().requires_grad_(x_grad)
+    ref = O.forward(ref_p, xr, edge_index, edge_texts, variant="factorised", dtype=torch.float64)
+    (ref * torch.from_numpy(gout).double()).sum().backward()
+    return model, ref_p, out, ref, x, xr
+
+
+@pytest.mark.parametrize("name,N,E,R,kind", [("small", 0, 0, 0, "toy"), ("mid32", 300, 2500, 6, "powerlaw"),
+                                             ("c2", 700, 6000, 9, "uniform"), ("c3", 900, 8000, 7, "powerlaw")])
+def test_model_backward_matches_autograd_of_the_oracle(name, N, E, R, kind):
+    """Every parameter gradient of HyperGNN.forward (text encoder, input projection, generators, log-scales, LayerNorms)
+    against torch.autograd through the float64 oracle — the reference trains by plain autograd (demo.py:79-101)."""
+    cfg = cases.MODELS[name]
+    if kind == "toy":
+        kg = ToyKnowledgeGraph(feat_dim=cfg.node_feat_dim)
+        nf, ei, texts = kg.node_features.numpy(), kg.edge_index.numpy(), kg.edge_texts
+    else:
+        g = synth.make_kg(N, E, R, cfg.node_feat_dim, seed=900 + N, kind=kind)
+        nf, ei, texts = g.node_features, g.edge_index, g.edge_texts()
+    gout = synth.normal(31, "gout", (nf.shape[0], cfg.hidden_dim))
+    model, ref_p, out, ref, x, xr = _model_grads(name, nf, ei, texts, gout, x_grad=(name != "c3"))
+    assert_close(out.detach().cpu().numpy(), ref.detach().float().numpy(), "training forward")
+    for k, p in model.named_parameters():
+        assert p.grad is not None, f"no gradient on {k}"
+        _grad_check(k, p.grad.cpu().numpy(), ref_p[k].grad.numpy())
+    if x.requires_grad:
+        _grad_check("node_features", x.grad.cpu().numpy(), xr.grad.numpy())
+    model.eval()
+    with torch.no_grad():                                               # the inference kernels agree with the recorded forward
+        assert_close(model(x.detach(), torch.from_numpy(ei).to(DEV), texts).cpu().numpy(), out.detach().cpu().numpy(), "eval")
+
+
+def test_training_like_the_reference_tests():
+    """reference tests/test_hypergnn.py:183-226 (backward runs, an SGD step changes parameters, the margin loss of
+    demo.py:79-101 goes down under Adam) on the HIP path."""
+    kg = ToyKnowledgeGraph(feat_dim=16)
+    x, ei = kg.node_features.to(DEV), kg.edge_index.to(DEV)
+    torch.manual_seed(0)
+    model = HyperGNN(text_dim=32, node_feat_dim=16, hidden_dim=16, num_layers=2).to(DEV)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    before = {n: p.clone().detach() for n, p in model.named_parameters()}
+    opt.zero_grad()
+    model(x, ei, kg.edge_texts).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    opt.step()
+    assert sum(not torch.equal(before[n], p.detach()) for n, p in model.named_parameters()) > 0
+    torch.manual_seed(1)
+    model = HyperGNN(text_dim=32, node_feat_dim=16, hidden_dim=16, num_layers=2).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    src, dst = ei
+    losses = []
+    for _ in range(15):
+        opt.zero_grad()
+        embs = model(x, ei, kg.edge_texts)
+        pos = model.score_triple(embs[src], embs[dst])
+        perm = torch.randperm(dst.size(0)).to(DEV)
+        neg = model.score_triple(embs[src], embs[dst[perm]])
+        loss = torch.clamp(1.0 - pos + neg, min=0.0).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses
+    a = torch.randn(9, 16, device=DEV, requires_grad=True)
+    b = torch.randn(9, 16, device=DEV, requires_grad=True)
+    g = torch.randn(9, device=DEV)
+    model.score_triple(a, b).backward(g)
+    assert torch.allclose(a.grad, g[:, None] * b.detach()) and torch.allclose(b.grad, g[:, None] * a.detach())
+
+
 def test_row_range_only_touches_its_rows(kernel):
     d, N, E, R = 128, 2000, 20000, 16
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=5, kind="uniform")
@@ -541,7 +658,7 @@ def test_errors_and_cache():
     with pytest.raises(ValueError):
         model(x, ei, kg.edge_texts[:-1])
     with pytest.raises(NotImplementedError):
-        model(x, ei, kg.edge_texts)                    # grad enabled + trainable parameters
+        model.forward_planned(x, model.plan_for(ei, kg.edge_texts, x.size(0), DEV))   # explicit plans: inference only
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             model(kg.node_features, kg.edge_index, kg.edge_texts)     # CPU tensors: no fallback
