@@ -59,6 +59,8 @@ SIGNATURES = {
     "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ghf_relu_mask": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "ghf_edge_outer_supported": (_i32, [_i32]),
+    "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "ghf_add3": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -361,6 +363,21 @@ def group_outer(A: Optional[torch.Tensor], ia: Optional[torch.Tensor], B: torch.
     _check(lib.ghf_group_outer(_ptr(A), _ptr(ia), da, _ptr(B), _ptr(ib), db, goff.data_ptr(), goff.data_ptr() + 8, ng,
                                _ptr(out), 1 if acc else 0, _stream()), "ghf_group_outer")
     return out
+
+
+def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, slice_tab: torch.Tensor,
+               slice_off: torch.Tensor, R: int):
+    """(dW [R, 2d, d] = dW_msg stacked on dW_self, db [R, d]) of include/ghf.h: ghf_edge_outer."""
+    lib = load()
+    h, G = _req(h, torch.float32, "h"), _req(G, torch.float32, "G")
+    d, ns = h.size(1), slice_tab.size(0)
+    ws = torch.empty(ns * (2 * d * d + d), dtype=torch.float32, device=h.device)
+    dW = torch.empty(R, 2 * d, d, dtype=torch.float32, device=h.device)
+    db = torch.empty(R, d, dtype=torch.float32, device=h.device)
+    _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), _ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")),
+                              _ptr(_req(slice_tab, torch.int64, "slice_tab")), _ptr(_req(slice_off, torch.int64, "slice_off")),
+                              ns, R, d, _ptr(ws), _ptr(dW), _ptr(db), _stream()), "ghf_edge_outer")
+    return dW, db
 
 
 _RANGES: dict = {}

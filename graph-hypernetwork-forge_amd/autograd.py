@@ -39,9 +39,13 @@ class TrainPlan:
     """What a training step needs beyond the forward plan: the reversed graph's plan and the edges grouped by relation."""
     fwd: GraphPlan
     rev: GraphPlan
-    src_by_rel: torch.Tensor      # [E] int64: source of the edges in relation order
+    src_by_rel: torch.Tensor      # [E] int64: source of the edges in relation order (ascending destination inside one)
     dst_by_rel: torch.Tensor      # [E] int64
     goff: torch.Tensor            # [R+1] int64
+    slice_tab: Optional[torch.Tensor] = None   # [S, 3] int64 (relation, first edge, end edge): ghf_edge_outer's work list
+    slice_off: Optional[torch.Tensor] = None   # [R+1] int64
+
+SLICE_EDGES = 4096                # edges per ghf_edge_outer workgroup (a multiple of its 32-edge tile)
 
 
 def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: GraphPlan, d: int, device) -> TrainPlan:
@@ -50,9 +54,21 @@ def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: Graph
     ei = edge_index.to(device=device, dtype=torch.int64)
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     rev = build_plan(ei.flip(0).contiguous(), rel, fwd.unique_texts, fwd.N, d, device)
-    perm, goff = _native.group_edges(rel, fwd.R)
-    return TrainPlan(fwd=fwd, rev=rev, src_by_rel=ei[0].index_select(0, perm).contiguous(),
-                     dst_by_rel=ei[1].index_select(0, perm).contiguous(), goff=goff)
+    by_dst = torch.sort(ei[1], stable=True).indices          # destinations ascending inside a relation: G / h_dst rows stay
+    perm, goff = _native.group_edges(rel.index_select(0, by_dst), fwd.R)   # hot in L2 while a slice is contracted
+    perm = by_dst.index_select(0, perm)
+    tp = TrainPlan(fwd=fwd, rev=rev, src_by_rel=ei[0].index_select(0, perm).contiguous(),
+                   dst_by_rel=ei[1].index_select(0, perm).contiguous(), goff=goff)
+    if _native.load().ghf_edge_outer_supported(d):
+        off = goff.cpu().tolist()                             # (one host sync per plan)
+        tab, soff = [], [0]
+        for r in range(fwd.R):
+            tab += [(r, a, min(a + SLICE_EDGES, off[r + 1])) for a in range(off[r], off[r + 1], SLICE_EDGES)]
+            soff.append(len(tab))
+        if tab:
+            tp.slice_tab = torch.tensor(tab, dtype=torch.int64).to(device)
+            tp.slice_off = torch.tensor(soff, dtype=torch.int64).to(device)
+    return tp
 
 
 def _layer_weights(plan: GraphPlan, Wm: Optional[torch.Tensor], Ws: Optional[torch.Tensor], transpose: bool):
@@ -108,9 +124,14 @@ class MessageLayerFn(torch.autograd.Function):
         dpre, G, T = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg)
         dgamma = _native.colsum(T)
         dbeta = _native.colsum(g)
-        dWm = _native.group_outer(h, tp.src_by_rel, G, tp.dst_by_rel, tp.goff)
-        dWs = _native.group_outer(h, tp.dst_by_rel, G, tp.dst_by_rel, tp.goff)
-        db = _native.group_outer(None, None, G, tp.dst_by_rel, tp.goff).reshape(plan.R, -1)
+        if tp.slice_tab is not None:
+            dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
+            d = h.size(1)
+            dWm, dWs = dW[:, :d], dW[:, d:]
+        else:
+            dWm = _native.group_outer(h, tp.src_by_rel, G, tp.dst_by_rel, tp.goff)
+            dWs = _native.group_outer(h, tp.dst_by_rel, G, tp.dst_by_rel, tp.goff)
+            db = _native.group_outer(None, None, G, tp.dst_by_rel, tp.goff).reshape(plan.R, -1)
         dh = None
         if ctx.needs_input_grad[0]:
             zero_b = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)

@@ -157,6 +157,171 @@ __global__ __launch_bounds__(256) void group_outer_kernel(const float* __restric
     }
 }
 
+// ---- per-relation weight gradients of a whole layer in one pass -------------------------------------------------------
+//   dW[r] = sum_{e in r} [h_src(e) | h_dst(e)]^T G_dst(e)    ([2D, D]: dWm on top of dWs),   db[r] = sum_{e in r} G_dst(e)
+// over edges grouped by relation and cut into slices (slice_tab: relation, first edge, end edge; a slice never crosses a
+// relation).  One workgroup per slice: tiles of ET edges are gathered into LDS as rows [h_src | h_dst] and G_dst (double
+// buffered, the next tile's rows in flight during this tile's MFMAs), and the workgroup keeps the whole [2D, D] partial
+// product in accumulators: wave (rg, cg) owns 64 x 64 of it as 4 x 4 tiles of v_mfma_f32_16x16x4_f32 whose operands are
+// single ds_read_b128 per k-step (lane (i, k) reads columns 4i..4i+3 of row k: register a feeds the tile of rows
+// {4i + a}).  Exact fp32; partial products are summed per relation in slice order by edge_outer_reduce_kernel.
+constexpr int EO_ET = 32;                                 // edges per tile
+
+template <int D>
+__global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kernel(
+    const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+    const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b) {
+    constexpr int RG = 2 * D / 64, CG = D / 64, NT = RG * CG * 64;
+    constexpr int F4 = D / 4;                             // float4 per row of h / G
+    constexpr int LPR = EO_ET * F4 / NT;                  // rows x float4 each thread moves per region and tile
+    constexpr int QN = NT / D, RQ = EO_ET / QN;           // db: QN groups of threads, RQ tile rows each
+    static_assert(LPR >= 1 && EO_ET * F4 % NT == 0 && NT % D == 0 && EO_ET % QN == 0, "tile does not divide");
+    extern __shared__ float eo_lds[];
+    float* Xt = eo_lds;                                   // [2][ET][2D]
+    float* Gt = eo_lds + 2 * EO_ET * 2 * D;               // [2][ET][D]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int rg = w / CG, cg = w % CG;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int64_t e0 = slice_tab[3 * (size_t)blockIdx.x + 1], e1 = slice_tab[3 * (size_t)blockIdx.x + 2];
+    const int ntiles = (int)((e1 - e0 + EO_ET - 1) / EO_ET);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int64_t is[LPR], id[LPR];                             // indices of the tile to gather next
+    f32x4 st[3][LPR];                                     // its rows on their way to LDS
+    auto load_idx = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int64_t e = e0 + (int64_t)tile * EO_ET + (t + NT * j) / F4;
+            const bool ok = e < e1;
+            is[j] = ok ? src[e] : -1;
+            id[j] = ok ? dst[e] : -1;
+        }
+    };
+    auto gather = [&]() {
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int c4 = (t + NT * j) % F4;
+            const bool ok = is[j] >= 0;
+            st[0][j] = ok ? *(const f32x4*)(h + (size_t)is[j] * D + 4 * c4) : zero4;
+            st[1][j] = ok ? *(const f32x4*)(h + (size_t)id[j] * D + 4 * c4) : zero4;
+            st[2][j] = ok ? *(const f32x4*)(G + (size_t)id[j] * D + 4 * c4) : zero4;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int row = (t + NT * j) / F4, c4 = (t + NT * j) % F4;
+            float* xr = Xt + ((size_t)buf * EO_ET + row) * 2 * D;
+            *(f32x4*)(xr + 4 * c4) = st[0][j];
+            *(f32x4*)(xr + D + 4 * c4) = st[1][j];
+            *(f32x4*)(Gt + ((size_t)buf * EO_ET + row) * D + 4 * c4) = st[2][j];
+        }
+    };
+
+    load_idx(0);
+    gather();
+    load_idx(1);                                          // (past the slice: every lane reads nothing)
+    commit(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        gather();                                         // tile + 1 (indices were loaded an iteration ago)
+        load_idx(tile + 2);
+        const float* Xb = Xt + (size_t)buf * EO_ET * 2 * D + rg * 64 + 4 * c16;
+        const float* Gb = Gt + (size_t)buf * EO_ET * D + cg * 64 + 4 * c16;
+#pragma unroll
+        for (int ks = 0; ks < EO_ET / 4; ++ks) {
+            const f32x4 a = *(const f32x4*)(Xb + (size_t)(4 * ks + q) * 2 * D);
+            const f32x4 b = *(const f32x4*)(Gb + (size_t)(4 * ks + q) * D);
+#pragma unroll
+            for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+                for (int bi = 0; bi < 4; ++bi)
+                    acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ai], b[bi], acc[ai][bi], 0, 0, 0);
+        }
+        {
+            const float* gcol = Gt + ((size_t)buf * EO_ET + (t / D) * RQ) * D + (t % D);
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) bsum += gcol[(size_t)r * D];
+        }
+        commit(buf ^ 1);
+        __syncthreads();
+    }
+    // partial product: tile (ai, bi) register s is row rg*64 + 4*(4q + s) + ai, column cg*64 + 4*c16 + bi
+    float* P = partial + (size_t)blockIdx.x * 2 * D * D;
+#pragma unroll
+    for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = rg * 64 + 4 * (4 * q + s) + ai;
+            *(f32x4*)(P + (size_t)row * D + cg * 64 + 4 * c16) = (f32x4){acc[ai][0][s], acc[ai][1][s], acc[ai][2][s], acc[ai][3][s]};
+        }
+    float* red = eo_lds;                                  // [QN][D] (every tile read is behind the loop's last barrier)
+    red[t] = bsum;
+    __syncthreads();
+    if (t < D) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < QN; ++k) s += red[k * D + t];
+        partial_b[(size_t)blockIdx.x * D + t] = s;
+    }
+}
+
+// dW[r] = sum of its slices' partial products in slice order (x: float4 of the [2D*D] matrix, y: relation); db likewise
+__global__ __launch_bounds__(256) void edge_outer_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
+                                                                const int64_t* __restrict__ slice_off, int d,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+    const int r = blockIdx.y;
+    const int64_t s0 = slice_off[r], s1 = slice_off[r + 1];
+    const int n4 = 2 * d * d / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = s0; k < s1; ++k) s += *(const f32x4*)(partial + (size_t)k * 2 * d * d + 4 * (size_t)i);
+        *(f32x4*)(dW + (size_t)r * 2 * d * d + 4 * (size_t)i) = s;
+    } else if (i - n4 < d) {
+        float s = 0.f;
+        for (int64_t k = s0; k < s1; ++k) s += partial_b[(size_t)k * d + (i - n4)];
+        db[(size_t)r * d + (i - n4)] = s;
+    }
+}
+
+template <int D>
+static int edge_outer_launch(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
+                             int64_t nslices, float* partial, float* partial_b, hipStream_t stream) {
+    constexpr int NT = (2 * D / 64) * (D / 64) * 64;
+    const size_t lds = (size_t)2 * EO_ET * 3 * D * sizeof(float);
+    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)edge_outer_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    edge_outer_kernel<D><<<(unsigned)nslices, NT, lds, stream>>>(h, G, src, dst, slice_tab, partial, partial_b);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int edge_outer_supported(int d) { return d == 64 || d == 128; }
+
+int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
+                      const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
+                      hipStream_t stream) {
+    GHF_REQUIRE(edge_outer_supported(d), "edge_outer: d = %d has no tile (64 and 128 do; use ghf_group_outer)", d);
+    GHF_REQUIRE(nslices > 0 && R > 0, "edge_outer: nothing to do");
+    float* partial = workspace;
+    float* partial_b = workspace + (size_t)nslices * 2 * d * d;
+    int rc = d == 128 ? edge_outer_launch<128>(h, G, src, dst, slice_tab, nslices, partial, partial_b, stream)
+                      : edge_outer_launch<64>(h, G, src, dst, slice_tab, nslices, partial, partial_b, stream);
+    if (rc != GHF_OK) return rc;
+    const unsigned gx = (unsigned)cdiv((int64_t)2 * d * d / 4 + d, 256);
+    edge_outer_reduce_kernel<<<dim3(gx, (unsigned)R), 256, 0, stream>>>(partial, partial_b, slice_off, d, dW, db);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 // out[b][j][i] = in[b][i][j]
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, int rows, int cols,
                                                                 float* __restrict__ out) {

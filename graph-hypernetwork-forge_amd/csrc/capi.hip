@@ -193,6 +193,15 @@ int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, c
     return launch_group_outer(A, ia, da, B, ib, db, gstart, gend, ngroups, C, accumulate, (hipStream_t)stream);
 }
 
+int ghf_edge_outer_supported(int d) { return edge_outer_supported(d); }
+
+int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
+                   const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
+                   void* stream) {
+    GHF_REQUIRE(h && G && src && dst && slice_tab && slice_off && workspace && dW && db, "edge_outer: null pointer argument");
+    return launch_edge_outer(h, G, src, dst, slice_tab, slice_off, nslices, R, d, workspace, dW, db, (hipStream_t)stream);
+}
+
 int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream) {
     GHF_REQUIRE((X && log_scale && out) || n == 0, "scale_exp: null pointer argument");
     return n > 0 ? launch_scale_exp(X, n, log_scale, out, (hipStream_t)stream) : GHF_OK;

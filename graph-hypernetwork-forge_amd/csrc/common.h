@@ -162,6 +162,10 @@ int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B
 int launch_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, hipStream_t stream);
 int launch_add3(const float* a, const float* b, const float* c, int64_t n, float* out, hipStream_t stream);
 int launch_rowscale(const float* X, const float* g, int64_t n, int d, float* out, hipStream_t stream);
+int edge_outer_supported(int d);
+int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
+                      const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
+                      hipStream_t stream);
 int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream);
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
                           float* acts, hipStream_t stream);

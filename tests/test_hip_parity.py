@@ -503,6 +503,39 @@ def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind)
         assert rel_l2 < 2e-5, f"d{name}: relative L2 {rel_l2:.3e}"
 
 
+@pytest.mark.parametrize("d,N,E,R", [(128, 700, 30000, 5), (64, 300, 9000, 3), (128, 50, 40, 4)])
+def test_edge_outer_matches_the_plain_contraction(d, N, E, R):
+    """ghf_edge_outer (all three per-relation gradients in one pass over sliced relation groups) against the same sums in
+    float64, including relations without edges, slices shorter than a tile and a hub destination."""
+    from graph_hypernetwork_forge_amd import autograd as A
+    rng = np.random.default_rng(d + E)
+    ei = rng.integers(0, N, size=(2, E))
+    ei[1, : E // 4] = 7                                             # a hub
+    rel = rng.integers(0, R - 1, size=E)                            # the last relation stays empty
+    h = synth.normal(11, "eo_h", (N, d))
+    G = synth.normal(12, "eo_g", (N, d))
+    t = lambda a: torch.from_numpy(a).to(DEV)                       # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    old = A.SLICE_EDGES
+    try:
+        A.SLICE_EDGES = 1024                                        # several slices per relation at this size
+        tp = A.build_train_plan(t(ei), t(rel), plan, d, DEV)
+    finally:
+        A.SLICE_EDGES = old
+    assert tp.slice_tab is not None and tp.slice_tab.size(0) >= min(R - 1, E // 1024)
+    dW, db = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
+    again = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
+    assert torch.equal(dW, again[0]) and torch.equal(db, again[1])   # fixed summation order
+    h64, G64 = h.astype(np.float64), G.astype(np.float64)
+    for r in range(R):
+        m = rel == r
+        X = np.concatenate([h64[ei[0, m]], h64[ei[1, m]]], axis=1)
+        want, want_b = X.T @ G64[ei[1, m]], G64[ei[1, m]].sum(axis=0)
+        scale = max(float(np.abs(want).max()), 1.0)
+        assert np.abs(dW[r].cpu().numpy() - want).max() < 2e-5 * scale, f"relation {r}"
+        assert np.abs(db[r].cpu().numpy() - want_b).max() < 2e-5 * max(float(np.abs(want_b).max()), 1.0)
+
+
 def _grad_check(name, got, want, rtol=2e-4, l2=5e-5):
     gw, gg = want.astype(np.float64), got.astype(np.float64)
     assert gg.shape == gw.shape, f"d{name}: shape {gg.shape} vs {gw.shape}"
