@@ -74,28 +74,49 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
     }
 }
 
-// out[o] = sum_v X[v][o] * (mask ? (mask[v][o] > 0) : 1), in two deterministic stages
-constexpr int CS_ROWS = 512;                              // rows per first-stage workgroup
-__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ X, const float* __restrict__ mask,
-                                                            int64_t N, int d, float* __restrict__ part) {
+// out[o] = sum_v X[v][o] * (mask ? (mask[v][o] > 0) : 1): a tree of fixed shape.  One pass cuts the rows into runs of
+// CS_ROWS; a workgroup covers a run and up to 256 column vectors (VW floats each): thread (rsub, c) walks rows
+// rsub, rsub + nsub, ... of its columns, and the nsub row lanes are added in order through LDS.  Passes repeat on the
+// partial sums until one workgroup per column tile is left.
+constexpr int CS_ROWS = 512;                              // rows per workgroup and pass
+template <int VW>
+__global__ __launch_bounds__(256) void colsum_pass_kernel(const float* __restrict__ X, const float* __restrict__ mask,
+                                                          int64_t N, int d, float* __restrict__ out, int accumulate) {
+    typedef float vec __attribute__((ext_vector_type(VW)));
+    __shared__ float red[256 * VW];
+    const int dv = d / VW;                                // column vectors per row
+    const int cols = dv - (int)blockIdx.y * 256 < 256 ? dv - (int)blockIdx.y * 256 : 256;   // ... of this tile
+    const int nsub = 256 / cols;
+    const int c = threadIdx.x % cols, rsub = threadIdx.x / cols;
     const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
     const int64_t r1 = r0 + CS_ROWS < N ? r0 + CS_ROWS : N;
-    for (int o = threadIdx.x; o < d; o += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) {
-            const float xv = X[(size_t)r * d + o];
-            s += (!mask || mask[(size_t)r * d + o] > 0.f) ? xv : 0.f;
+    const size_t col = ((size_t)blockIdx.y * 256 + c) * VW;
+    vec s;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) s[k] = 0.f;
+    if (rsub < nsub)
+        for (int64_t r = r0 + rsub; r < r1; r += nsub) {
+            const vec xv = *(const vec*)(X + (size_t)r * d + col);
+            if (mask) {
+                const vec mv = *(const vec*)(mask + (size_t)r * d + col);
+#pragma unroll
+                for (int k = 0; k < VW; ++k) s[k] += mv[k] > 0.f ? xv[k] : 0.f;
+            } else {
+                s += xv;
+            }
         }
-        part[(size_t)blockIdx.x * d + o] = s;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) red[threadIdx.x * VW + k] = s[k];
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            float tot = 0.f;
+            for (int j = 0; j < nsub; ++j) tot += red[(j * cols + c) * VW + k];
+            float* dst = out + (size_t)blockIdx.x * d + col + k;
+            *dst = accumulate ? *dst + tot : tot;
+        }
     }
-}
-__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int64_t nblk, int d,
-                                                            float* __restrict__ out, int accumulate) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= d) return;
-    float s = 0.f;
-    for (int64_t b = 0; b < nblk; ++b) s += part[(size_t)b * d + o];
-    out[o] = accumulate ? out[o] + s : s;
 }
 
 // dmask[v][o] = X[v][o] * (ref[v][o] > 0)   (ReLU backward as a matrix, for the contractions below)
@@ -349,15 +370,32 @@ int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const 
     return GHF_OK;
 }
 
-size_t colsum_workspace_floats(int64_t N, int d) { return (size_t)cdiv(N, CS_ROWS) * d; }
+
+size_t colsum_workspace_floats(int64_t N, int d) {         // two ping-pong levels of partial sums
+    const int64_t n1 = cdiv(N, CS_ROWS);
+    return (size_t)(n1 + cdiv(n1, CS_ROWS)) * (size_t)d;
+}
 
 int launch_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, hipStream_t stream) {
     GHF_REQUIRE(N > 0 && d > 0, "colsum: bad shape");
-    const int64_t nblk = cdiv(N, CS_ROWS);
-    colsum_stage1_kernel<<<(unsigned)nblk, 256, 0, stream>>>(X, mask, N, d, workspace);
-    GHF_LAUNCH_CHECK();
-    colsum_stage2_kernel<<<(unsigned)cdiv(d, 256), 256, 0, stream>>>(workspace, nblk, d, out, accumulate);
-    GHF_LAUNCH_CHECK();
+    const bool v4 = (d % 4) == 0 && ((((uintptr_t)X | (uintptr_t)mask | (uintptr_t)workspace) & 15) == 0);
+    const unsigned gy = (unsigned)cdiv(v4 ? d / 4 : d, 256);
+    const float* in = X;
+    int64_t rows = N;
+    float* level[2] = {workspace, workspace + (size_t)cdiv(N, CS_ROWS) * d};
+    for (int pass = 0;; ++pass) {
+        const int64_t nblk = cdiv(rows, CS_ROWS);
+        const bool last = nblk == 1;
+        float* dst = last ? out : level[pass & 1];
+        const float* m = pass == 0 ? mask : nullptr;
+        const int acc = last ? accumulate : 0;
+        if (v4) colsum_pass_kernel<4><<<dim3((unsigned)nblk, gy), 256, 0, stream>>>(in, m, rows, d, dst, acc);
+        else colsum_pass_kernel<1><<<dim3((unsigned)nblk, gy), 256, 0, stream>>>(in, m, rows, d, dst, acc);
+        GHF_LAUNCH_CHECK();
+        if (last) break;
+        in = dst;
+        rows = nblk;
+    }
     return GHF_OK;
 }
 

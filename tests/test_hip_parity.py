@@ -536,6 +536,37 @@ def test_edge_outer_matches_the_plain_contraction(d, N, E, R):
         assert np.abs(db[r].cpu().numpy() - want_b).max() < 2e-5 * max(float(np.abs(want_b).max()), 1.0)
 
 
+@pytest.mark.parametrize("N,d", [(1, 8), (700, 128), (300000, 20), (1500, 4100), (270000, 128), (513, 7)])
+def test_backward_helpers_match_numpy(N, d):
+    """ghf_colsum (masked, accumulating, several tree levels, widths that are not a multiple of 4 or wider than one
+    column tile), ghf_dot, ghf_add3, ghf_rowscale, ghf_scale_exp, ghf_relu_mask, ghf_transpose_batched, matmul_tn."""
+    X, M = synth.normal(41, "cs_x", (N, d)), synth.normal(42, "cs_m", (N, d))
+    t = lambda a: torch.from_numpy(a).to(DEV)                       # noqa: E731
+    tol = lambda want: 3e-6 * max(1.0, float(np.abs(want).max())) * np.sqrt(N)   # noqa: E731
+    want = X.astype(np.float64).sum(axis=0)
+    got = _native.colsum(t(X))
+    assert np.abs(got.cpu().numpy() - want).max() < tol(want)
+    assert torch.equal(got, _native.colsum(t(X)))
+    wantm = (X.astype(np.float64) * (M > 0)).sum(axis=0)
+    acc = torch.ones(d, device=DEV)
+    _native.colsum(t(X), mask=t(M), out=acc)
+    assert np.abs(acc.cpu().numpy() - 1.0 - wantm).max() < tol(wantm)
+    wd = float((X.astype(np.float64) * M).sum())
+    assert abs(float(_native.dot(t(X), t(M))) - wd) < 1e-5 * max(1.0, abs(wd)) + 1e-6 * np.sqrt(N * d)
+    assert torch.equal(_native.add3(t(X), t(M), t(X)), (t(X) + t(M)) + t(X)) and torch.equal(_native.add3(t(X), t(M)), t(X) + t(M))
+    g = synth.normal(43, "cs_g", (N,))
+    assert torch.equal(_native.rowscale(t(X), t(g)), t(X) * t(g)[:, None])
+    ls = torch.tensor([-0.7], device=DEV)
+    assert torch.allclose(_native.scale_exp(t(X), ls), t(X) * ls.exp(), rtol=1e-6, atol=0)
+    assert torch.equal(_native.relu_mask(t(X), t(M)), torch.where(t(M) > 0, t(X), torch.zeros_like(t(X))))
+    if N * d < 4_000_000:
+        assert torch.equal(_native.transpose_batched(t(X)[None]), t(X).t().contiguous()[None])
+        Bm = synth.normal(44, "cs_b", (N, 24))
+        wmm = X.astype(np.float64).T @ Bm.astype(np.float64)
+        gmm = _native.matmul_tn(t(X), t(Bm)).cpu().numpy()
+        assert np.abs(gmm - wmm).max() < tol(wmm)
+
+
 def _grad_check(name, got, want, rtol=2e-4, l2=5e-5):
     gw, gg = want.astype(np.float64), got.astype(np.float64)
     assert gg.shape == gw.shape, f"d{name}: shape {gg.shape} vs {gw.shape}"
