@@ -3,8 +3,12 @@
 The path shards by DESTINATION node: a rank owns every in-edge of its rows, so each edge is
 owned by exactly one rank, the per-destination sums never cross ranks and the fused tail
 stays local.  The one real exchange step per layer is making the new h visible everywhere:
-an all-gather of fp32 rows over xGMI (half the bytes of the all-reduce an edge-range
-partition would need — SURVEY.md §8e).
+an all-gather of rows over xGMI (half the bytes of the all-reduce an edge-range
+partition would need — SURVEY.md §8e).  What travels is what the next layer's kernel gathers:
+for the default d = 128 kernel the rows already cut into their two fp16 pieces plus the row
+scales (written by the layer kernel's fused tail, 4 d + 4 bytes per row, the same volume as
+fp32), so no rank ever re-splits the full h; fp32 rows travel only after the last layer, and
+for the kernels that gather fp32 rows themselves.
 
 Ownership is block-cyclic so that the exchange overlaps the compute: the (padded) rows are cut
 into C chunks of G*S rows, and inside chunk c rank g owns rows [(c*G+g)*S, (c*G+g+1)*S)
@@ -89,11 +93,26 @@ class NativeOps:
         """What the message kernel gathers: h itself, or its rows cut into 16-bit pieces."""
         return _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
 
-    def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int) -> None:
+    # -- exchanging the split form (SPLIT2H: N rows of 4d bytes, then N float scales) ---------------------
+    def exchanges_split(self, plan) -> bool:
+        return plan.wlayout == _native.WLAYOUT_SPLIT2H
+
+    def alloc_split(self, plan, N: int, d: int, device) -> torch.Tensor:
+        return _native.alloc_split(N, d, plan.wlayout, device)
+
+    def split_parts(self, plan, hs: torch.Tensor, N: int, d: int) -> List[torch.Tensor]:
+        """The row-indexed regions of a split buffer as [N, bytes] views: what the exchange moves."""
+        b = hs.view(torch.uint8)
+        return [b[: N * 4 * d].view(N, 4 * d), b[N * 4 * d: N * 4 * d + 4 * N].view(N, 4)]
+
+    def split_range(self, plan, h, hs, lo: int, hi: int) -> None:
+        _native.split_rows(h, plan.wlayout, out=hs, row0=lo, rows=hi - lo)
+
+    def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int, h_split_out=None) -> None:
         norm = model.layer_norms[l]
         W, W_self, bias = weights
         _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(), norm.bias.detach(),
-                                  norm.eps, h_out, row0=lo, rows=hi - lo, h_split=h_split)
+                                  norm.eps, h_out, row0=lo, rows=hi - lo, h_split=h_split, h_split_out=h_split_out)
 
 
 class ShardedHyperGNN:
@@ -113,8 +132,20 @@ class ShardedHyperGNN:
 
     # -- exchange ---------------------------------------------------------------------------------------
     def _gather_chunk(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
-        """In-place all-gather of chunk c: rank g contributes its slot of the contiguous chunk slice."""
+        """All-gather of chunk c of a row-indexed buffer: rank g contributes its slot of the contiguous chunk slice.
+        In place when the buffer has the padded rows; a buffer of exactly N rows takes the chunk that reaches past N
+        through a staging copy."""
         lo, hi = spec.chunk_rows(c)
+        if hi > buf.size(0):
+            stage = torch.empty((hi - lo,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+            a, b = spec.slot(c)
+            if b > a:
+                stage[a - lo: b - lo].copy_(buf[a:b])
+            self._gather_chunk(stage, ShardSpec(N=hi - lo, world=spec.world, rank=spec.rank, block_nodes=spec.block_nodes,
+                                                chunks=1, S=spec.S), 0)
+            if buf.size(0) > lo:
+                buf[lo:].copy_(stage[: buf.size(0) - lo])
+            return
         whole = buf[lo:hi]
         mine = buf[lo + spec.rank * spec.S: lo + (spec.rank + 1) * spec.S]
         if buf.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -129,8 +160,11 @@ class ShardedHyperGNN:
             parts = [buf[lo + g * spec.S: lo + (g + 1) * spec.S] for g in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)
 
-    def _run_chunked(self, buf: torch.Tensor, spec: ShardSpec, compute_rows) -> None:
-        """compute_rows(lo, hi) fills my rows of a chunk; its gather overlaps the next chunk's compute."""
+    def _run_chunked(self, bufs, spec: ShardSpec, compute_rows) -> None:
+        """compute_rows(lo, hi) fills my rows of a chunk in every buffer of `bufs`; the chunk's gathers overlap the next
+        chunk's compute."""
+        bufs = [bufs] if isinstance(bufs, torch.Tensor) else list(bufs)
+        buf = bufs[0]
         on_gpu = buf.is_cuda
         if on_gpu:
             if self._comm_stream is None:
@@ -146,9 +180,11 @@ class ShardedHyperGNN:
                 ready.record(main)
                 with torch.cuda.stream(self._comm_stream):
                     self._comm_stream.wait_event(ready)
-                    self._gather_chunk(buf, spec, c)
+                    for b in bufs:
+                        self._gather_chunk(b, spec, c)
             else:
-                self._gather_chunk(buf, spec, c)
+                for b in bufs:
+                    self._gather_chunk(b, spec, c)
         if on_gpu:
             main.wait_stream(self._comm_stream)                # every row of `buf` is in place for the next layer
 
@@ -178,6 +214,8 @@ class ShardedHyperGNN:
         h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
         h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
+        if self.ops.exchanges_split(plan):
+            return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
         self._run_chunked(h, spec, lambda lo, hi: self.ops.input_proj(model, node_features[lo:hi], h[lo:hi]))
         for l in range(model.num_layers):
             weights = self.ops.layer_weights(model, l, text_embs, plan)
@@ -186,6 +224,29 @@ class ShardedHyperGNN:
             self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], src_split, plan,
                                                                             dst[:N], lo, hi))
             h, h_next = h_next, h
+        return h[:N]
+
+    def _forward_split(self, node_features, plan, spec, text_embs, h, h_next) -> torch.Tensor:
+        """Layers whose kernel gathers pre-split rows: a rank keeps fp32 h for its own rows only (the residual input of
+        the next layer) and the ranks exchange the split rows their fused tails wrote; fp32 rows travel once, at the end."""
+        model, ops = self.model, self.ops
+        N, d, device = node_features.size(0), model.hidden_dim, node_features.device
+        hs, hs_next = ops.alloc_split(plan, N, d, device), ops.alloc_split(plan, N, d, device)
+
+        def project(lo, hi):
+            ops.input_proj(model, node_features[lo:hi], h[lo:hi])
+            ops.split_range(plan, h[:N], hs, lo, hi)
+        self._run_chunked(ops.split_parts(plan, hs, N, d), spec, project)
+        last = model.num_layers - 1
+        for l in range(model.num_layers):
+            weights = ops.layer_weights(model, l, text_embs, plan)
+            src, dst, src_split = h, h_next, hs
+            out_split = None if l == last else hs_next
+            self._run_chunked(dst if l == last else ops.split_parts(plan, hs_next, N, d), spec,
+                              lambda lo, hi: ops.layer_rows(model, l, weights, src[:N], src_split, plan, dst[:N], lo, hi,
+                                                            h_split_out=out_split))
+            h, h_next = h_next, h
+            hs, hs_next = hs_next, hs
         return h[:N]
 
     __call__ = forward

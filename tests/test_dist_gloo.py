@@ -25,8 +25,9 @@ from oracle import hypergnn_oracle as O
 class OracleOps:
     """Same interface as dist.NativeOps, computed by the oracle on CPU tensors."""
 
-    def __init__(self, block_nodes):
+    def __init__(self, block_nodes, split=False):
         self.bn = block_nodes
+        self.split = split           # emulate a kernel that gathers a split form: here the fp32 bits + a row "scale" of 1
 
     def message_config(self, d):
         return self.bn, 0, 48, 128
@@ -53,11 +54,35 @@ class OracleOps:
     def split_rows(self, plan, h):
         return None
 
-    def layer_rows(self, model, l, w, h, h_split, plan, h_out, lo, hi):
+    # the split exchange of dist.NativeOps with a stand-in split form: N rows of the fp32 bytes, then N float ones
+    def exchanges_split(self, plan):
+        return self.split
+
+    def alloc_split(self, plan, N, d, device):
+        return torch.full((N * d + N,), float("nan"))
+
+    def split_parts(self, plan, hs, N, d):
+        b = hs.view(torch.uint8)
+        return [b[: N * 4 * d].view(N, 4 * d), b[N * 4 * d:].view(N, 4)]
+
+    def split_range(self, plan, h, hs, lo, hi):
+        N, d = h.shape
+        hs[: N * d].view(N, d)[lo:hi] = h[lo:hi]
+        hs[N * d:][lo:hi] = 1.0
+
+    def layer_rows(self, model, l, w, h, h_split, plan, h_out, lo, hi, h_split_out=None):
         p = self._params(model)
+        if self.split:                                               # other ranks' rows exist in the split form only
+            N, d = h.shape
+            assert bool((h_split[N * d:] == 1.0).all()), "a row scale did not arrive"
+            full = h_split[: N * d].view(N, d)
+            assert torch.equal(full[lo:hi], h[lo:hi])
+            h = full
         agg = O.message_passing_factorised(h, plan.ei, plan.rel, w["W_msg"], w["W_self"], w["bias"])
         out = O.layer_tail(agg, h, p[f"layer_norms.{l}.weight"], p[f"layer_norms.{l}.bias"])
         h_out[lo:hi] = out[lo:hi]
+        if h_split_out is not None:
+            self.split_range(plan, h_out, h_split_out, lo, hi)
 
 
 def _free_port():
@@ -66,7 +91,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, block_nodes, chunks, ret):
+def _worker(rank, world, port, case_name, block_nodes, chunks, split, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,7 +100,7 @@ def _worker(rank, world, port, case_name, block_nodes, chunks, ret):
         cfg = cases.MODELS[case.model]
         model = HyperGNN(cfg.text_dim, cfg.node_feat_dim, cfg.hidden_dim, cfg.num_layers).eval()
         model.load_state_dict({k: torch.from_numpy(v) for k, v in cfg.params().items()})
-        runner = ShardedHyperGNN(model, ops=OracleOps(block_nodes), chunks=chunks)
+        runner = ShardedHyperGNN(model, ops=OracleOps(block_nodes, split), chunks=chunks)
         x, ei = torch.from_numpy(case.node_features), torch.from_numpy(case.edge_index)
         out = runner(x, ei, case.edge_texts)
         out2 = runner(x, ei, case.edge_texts)                         # second call reuses the shard plan
@@ -87,13 +112,16 @@ def _worker(rank, world, port, case_name, block_nodes, chunks, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name,bn,chunks", [(2, "g3_mid32", 216, 4), (3, "g3_mid32", 64, 3), (2, "g3_mid32", 64, 1),
-                                                        (2, "g2_toy", 8, 4), (3, "g2_chain", 4, 2)])
-def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn, chunks):
+@pytest.mark.parametrize("world,case_name,bn,chunks,split", [
+    (2, "g3_mid32", 216, 4, False), (3, "g3_mid32", 64, 3, False), (2, "g3_mid32", 64, 1, False), (2, "g2_toy", 8, 4, False),
+    (3, "g2_chain", 4, 2, False), (2, "g3_mid32", 216, 4, True), (3, "g3_mid32", 64, 3, True), (3, "g2_chain", 4, 2, True)])
+def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn, chunks, split):
+    """split=True: the exchange moves the (stand-in) split rows and their scales, fp32 rows only after the last layer —
+    the schedule dist.NativeOps runs for the default d = 128 kernel."""
     g = np.load(os.path.join(golden_dir, f"{case_name}.npz"))
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), case_name, bn, chunks, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case_name, bn, chunks, split, ret), nprocs=world, join=True)
     assert sorted(ret.keys()) == list(range(world))
     for r in range(world):
         assert_close(ret[r], g["out"], f"{case_name} world={world} rank={r}")

@@ -829,10 +829,10 @@ def _two_rank_worker(rank, world, port, name, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("g6_c3", 2), ("g5_c2", 3)])
+@pytest.mark.parametrize("name,world", [("g6_c3", 2), ("g5_c2", 3), ("g6_c3", 3)])
 def test_sharded_forward_multi_rank_on_one_gpu(golden_dir, name, world):
-    """The whole multi-rank product path — ownership-filtered plans, chunked launches, per-layer exchange, row
-    splitting after the exchange — with real HIP kernels on every rank: `world` processes share this GPU and exchange
+    """The whole multi-rank product path — ownership-filtered plans, chunked launches, per-layer exchange (of the split
+    rows the fused tails write at d = 128, of fp32 rows plus a re-split at d = 64) — with real HIP kernels on every rank: `world` processes share this GPU and exchange
     through gloo (NCCL refuses two ranks on one device); every rank must reproduce the reference."""
     import socket
     import torch.multiprocessing as mp
