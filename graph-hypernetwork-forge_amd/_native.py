@@ -129,7 +129,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw getter: torch.cuda.current_stream() without a device index walks through torch.cuda.is_available()
+    # (environment lookups, ~40 us per launch on the GPU box — more than most of these kernels' launch cost)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
