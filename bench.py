@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="single GPU: a step replays the captured HIP graph of the warm forward (HyperGNN.graphed)")
     ap.add_argument("--kernel-reps", type=int, default=10, help="timed launches of the message kernel for the roofline")
     args = ap.parse_args()
 
@@ -135,7 +137,11 @@ def main():
 
     runner = ShardedHyperGNN(model) if world > 1 else None
 
+    graphed = model.graphed(x, edge_index, edge_texts) if (args.hip_graph and world == 1) else None
+
     def step():
+        if graphed is not None:
+            return graphed.replay()
         with torch.no_grad():
             return runner(x, edge_index, edge_texts) if runner else model(x, edge_index, edge_texts)
 
@@ -234,6 +240,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["desc"], "nodes": N, "edges": E, "relations": R, "hidden_dim": d,
                        "layers": L, "text_dim": T, "plan": "cached (warm)",
+                       "launch": "captured HIP graph replay" if graphed is not None else "one C-ABI call per kernel",
                        "parallelism": "single GPU" if world == 1 else f"block-cyclic destination shards x{world}, chunked all-gather of h per layer overlapped with compute"},
             "cold_forward_ms": t_cold * 1e3, "setup_s": t_setup,
             "whole_forward_hbm_gbs": (L * layer_bytes(N, E, R, d) + 2 * N * d * 4) / (ms_step * 1e-3) / 1e9,

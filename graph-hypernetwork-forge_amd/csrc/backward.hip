@@ -319,7 +319,7 @@ static int edge_outer_launch(const float* h, const float* G, const int64_t* src,
                              int64_t nslices, float* partial, float* partial_b, hipStream_t stream) {
     constexpr int NT = (2 * D / 64) * (D / 64) * 64;
     const size_t lds = (size_t)2 * EO_ET * 3 * D * sizeof(float);
-    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)edge_outer_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GHF_SET_MAX_LDS(edge_outer_kernel<D>, lds);
     edge_outer_kernel<D><<<(unsigned)nslices, NT, lds, stream>>>(h, G, src, dst, slice_tab, partial, partial_b);
     GHF_LAUNCH_CHECK();
     return GHF_OK;

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -23,6 +24,18 @@ int set_err(int code, const char* fmt, ...);
     } while (0)
 
 #define GHF_LAUNCH_CHECK() GHF_HIP_CHECK(hipGetLastError())
+
+// Raise a kernel's dynamic-LDS limit once per process and size (one process drives one GPU), not per launch: the
+// launch path stays free of non-stream API calls, so a warm forward can be captured into a HIP graph.
+#define GHF_SET_MAX_LDS(kernel, bytes)                                                                          \
+    do {                                                                                                        \
+        static std::atomic<int> _ghf_lds_set{-1};                                                               \
+        const int _ghf_b = (int)(bytes);                                                                        \
+        if (_ghf_lds_set.load(std::memory_order_acquire) < _ghf_b) {                                            \
+            GHF_HIP_CHECK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, _ghf_b)); \
+            _ghf_lds_set.store(_ghf_b, std::memory_order_release);                                              \
+        }                                                                                                       \
+    } while (0)
 
 #define GHF_REQUIRE(cond, ...)                                                           \
     do {                                                                                 \

@@ -583,7 +583,7 @@ static int launch_hx_for(const MsgArgs& a, hipStream_t stream) {
                     (uint64_t)a.R * (2 * D * D * 4 + 4) < (1ull << 32),
                 "message(hx): 32-bit byte offsets need N*(4d+4), E*4 and R*(8d*d+4) below 4 GiB");
     static const int dbg = getenv("GHF_DEBUG_FLAGS") ? atoi(getenv("GHF_DEBUG_FLAGS")) : 0;   // honoured by -DGHF_ABLATE builds only
-    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_hx_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GHF_SET_MAX_LDS(message_hx_kernel<D>, lds);
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(hx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(hx): split blocks need the `partial` scratch");
     message_hx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,

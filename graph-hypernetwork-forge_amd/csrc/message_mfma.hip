@@ -427,7 +427,7 @@ static int launch_for(const MsgArgs& a, hipStream_t stream) {
     const int64_t row_end = a.row0 + a.rows;
     GHF_REQUIRE(row_end == a.N || row_end % C::BN == 0, "message(mfma): row range must end on a block boundary or at N");
     if (a.rows <= 0) return GHF_OK;
-    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GHF_SET_MAX_LDS(message_mfma_kernel<D>, lds);
     const unsigned grid = (unsigned)cdiv(a.rows, C::BN);
     static const int dbg = getenv("GHF_DEBUG_FLAGS") ? atoi(getenv("GHF_DEBUG_FLAGS")) : 0;   // diagnostic ablations, see DESIGN.md
     message_mfma_kernel<D><<<grid, C::NW * 64, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.blk_chunk_off,

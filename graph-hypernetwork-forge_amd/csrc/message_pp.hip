@@ -495,7 +495,7 @@ static int launch_pp_for(const MsgArgs& a, hipStream_t stream) {
     if (a.rows <= 0) return GHF_OK;
     GHF_REQUIRE((uint64_t)a.N * D * 4 < (1ull << 32) && (uint64_t)a.E * 4 < (1ull << 32) && (uint64_t)a.R * 2 * D * D * 4 < (1ull << 32),
                 "message(pp): 32-bit byte offsets need N*d*4, E*4 and R*2*d*d*4 below 4 GiB");
-    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_pp_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GHF_SET_MAX_LDS(message_pp_kernel<D>, lds);
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(pp): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(pp): split blocks need the `partial` scratch");
     message_pp_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,

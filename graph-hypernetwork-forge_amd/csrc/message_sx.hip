@@ -509,7 +509,7 @@ static int launch_sx_for(const MsgArgs& a, hipStream_t stream) {
     GHF_REQUIRE((uint64_t)a.N * D * 4 < (1ull << 32) && (uint64_t)a.E * 4 < (1ull << 32) && (uint64_t)a.R * 2 * D * D * 6 < (1ull << 32),
                 "message(sx): 32-bit byte offsets need N*d*4, E*4 and R*2*d*d*6 below 4 GiB");
     static const int dbg = getenv("GHF_DEBUG_FLAGS") ? atoi(getenv("GHF_DEBUG_FLAGS")) : 0;   // honoured by -DGHF_ABLATE builds only
-    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)message_sx_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GHF_SET_MAX_LDS(message_sx_kernel<D>, lds);
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(sx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(sx): split blocks need the `partial` scratch");
     GHF_REQUIRE(a.h_split, "message(sx): h_split is missing");

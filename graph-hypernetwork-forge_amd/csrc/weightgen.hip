@@ -321,7 +321,7 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
     wg_combine_kernel<<<dim3(32, (unsigned)R), 256, 0, stream>>>(top, bottom, transpose, d, out);
     GHF_LAUNCH_CHECK();
     const size_t lds = (size_t)2 * d * d * 4;
-    GHF_HIP_CHECK(hipFuncSetAttribute((const void*)wg_pack2h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
     wg_pack2h_kernel<<<R, 1024, lds, stream>>>(out, out + (size_t)R * 2 * d * d, d);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
@@ -395,7 +395,7 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
     }
     if (layout == GHF_WLAYOUT_SPLIT2H) {
         const size_t lds = (size_t)2 * n_mat * 4;
-        GHF_HIP_CHECK(hipFuncSetAttribute((const void*)wg_pack2h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
         wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out);
         GHF_LAUNCH_CHECK();
     }

@@ -684,6 +684,32 @@ def test_training_like_the_reference_tests():
     assert torch.allclose(a.grad, g[:, None] * b.detach()) and torch.allclose(b.grad, g[:, None] * a.detach())
 
 
+@pytest.mark.parametrize("name", ["small", "c2", "c3"])
+def test_captured_hip_graph_replays_the_forward(name):
+    """HyperGNN.graphed: the warm forward captured into a HIP graph gives the eager result bit for bit, follows new
+    features copied into its input and parameters updated in place."""
+    cfg = cases.MODELS[name]
+    g = synth.make_kg(1500, 12000, 6, cfg.node_feat_dim, seed=77, kind="powerlaw")
+    model = make_model(cfg)
+    x, ei, texts = torch.from_numpy(g.node_features).to(DEV), torch.from_numpy(g.edge_index).to(DEV), g.edge_texts()
+    with torch.no_grad():
+        eager = model(x, ei, texts).clone()
+    graphed = model.graphed(x, ei, texts)
+    assert torch.equal(graphed.replay(), eager)
+    x2 = torch.from_numpy(synth.normal(78, "x2", tuple(x.shape))).to(DEV)
+    with torch.no_grad():
+        eager2 = model(x2, ei, texts).clone()
+        assert not torch.equal(eager2, eager)
+    assert torch.equal(graphed.replay(x2), eager2)
+    with torch.no_grad():
+        model.layer_norms[0].bias.add_(0.5)
+        model.weight_generators[0].log_scales["W_msg"].add_(0.3)
+        eager3 = model(x2, ei, texts).clone()
+    assert torch.equal(graphed(), eager3) and not torch.equal(eager3, eager2)
+    with pytest.raises(ValueError):
+        graphed.replay(x2[:-1])
+
+
 def test_row_range_only_touches_its_rows(kernel):
     d, N, E, R = 128, 2000, 20000, 16
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=5, kind="uniform")
