@@ -86,8 +86,9 @@ class NativeOps:
     def input_proj(self, model, x_rows: torch.Tensor, out_rows: torch.Tensor) -> None:
         _native.input_proj_fwd(x_rows, model.input_proj.weight.detach(), model.input_proj.bias.detach(), out=out_rows)
 
-    def layer_weights(self, model, l: int, text_embs, plan):
-        return model.weight_generators[l].generate(text_embs, plan.wlayout)
+    def all_weights(self, model, text_embs, plan):
+        """([weights of layer l], [event l] or None): every layer's generation on a side stream (HyperGNN.generate_all)."""
+        return model.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= model.SIDE_STREAM_MIN_EDGES // 8)
 
     def split_rows(self, plan, h):
         """What the message kernel gathers: h itself, or its rows cut into 16-bit pieces."""
@@ -233,11 +234,14 @@ class ShardedHyperGNN:
         h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
         h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
+        all_w, ready = self.ops.all_weights(model, text_embs, plan)
         if self.ops.exchanges_split(plan):
-            return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
+            return self._forward_split(node_features, plan, spec, all_w, ready, h, h_next)
         self._run_chunked(h, spec, lambda lo, hi: self.ops.input_proj(model, node_features[lo:hi], h[lo:hi]))
         for l in range(model.num_layers):
-            weights = self.ops.layer_weights(model, l, text_embs, plan)
+            if ready is not None and ready[l] is not None:
+                torch.cuda.current_stream(device).wait_event(ready[l])
+            weights = all_w[l]
             src, dst = h, h_next
             src_split = self.ops.split_rows(plan, src[:N])          # all rows are in place after the previous exchange
             self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], src_split, plan,
@@ -245,7 +249,7 @@ class ShardedHyperGNN:
             h, h_next = h_next, h
         return h[:N]
 
-    def _forward_split(self, node_features, plan, spec, text_embs, h, h_next) -> torch.Tensor:
+    def _forward_split(self, node_features, plan, spec, all_w, ready, h, h_next) -> torch.Tensor:
         """Layers whose kernel gathers pre-split rows: a rank keeps fp32 h for its own rows only (the residual input of
         the next layer) and the ranks exchange the split rows their fused tails wrote; fp32 rows travel once, at the end."""
         model, ops = self.model, self.ops
@@ -258,7 +262,9 @@ class ShardedHyperGNN:
         self._run_chunked(ops.split_parts(plan, hs, N, d), spec, project)
         last = model.num_layers - 1
         for l in range(model.num_layers):
-            weights = ops.layer_weights(model, l, text_embs, plan)
+            if ready is not None and ready[l] is not None:
+                torch.cuda.current_stream(device).wait_event(ready[l])
+            weights = all_w[l]
             src, dst, src_split = h, h_next, hs
             out_split = None if l == last else hs_next
             self._run_chunked(dst if l == last else ops.split_parts(plan, hs_next, N, d), spec,

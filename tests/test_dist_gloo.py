@@ -47,9 +47,10 @@ class OracleOps:
     def input_proj(self, model, x_rows, out_rows):
         out_rows.copy_(torch.relu(x_rows @ model.input_proj.weight.t() + model.input_proj.bias))
 
-    def layer_weights(self, model, l, text_embs, plan):
+    def all_weights(self, model, text_embs, plan):
         d = model.hidden_dim
-        return O.weight_generator(self._params(model), f"weight_generators.{l}.", text_embs, d, d)
+        return [O.weight_generator(self._params(model), f"weight_generators.{l}.", text_embs, d, d)
+                for l in range(model.num_layers)], None
 
     def split_rows(self, plan, h):
         return None
