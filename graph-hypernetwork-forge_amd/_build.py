@@ -29,6 +29,9 @@ if VARIANT == "ablate":
 _b = _re.search(r"baux(\d+)", VARIANT)
 if _b:
     FLAGS.append("-DGHF_B_AUX=" + _b.group(1))
+_t = _re.search(r"opt(\d+)", VARIANT)
+if _t:
+    FLAGS.append("-DGHF_OPT=" + _t.group(1))          # A/B switches of message_hx.hip (see GHF_OPT there)
 _m = _re.search(r"exp(\d+)", VARIANT)
 if _m:
     # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags

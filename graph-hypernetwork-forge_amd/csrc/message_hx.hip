@@ -76,6 +76,11 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #ifndef GHF_B_AUX
 #define GHF_B_AUX 0          // cache policy bits of the weight loads (experiment)
 #endif
+#ifndef GHF_OPT
+#define GHF_OPT 0            // A/B switches (GHF_VARIANT=opt<mask>, same results; tools/ab.sh): none at the moment.
+                             // Tried this way and measured slower on one box: next tail batch's reads issued early (3.88 vs
+                             // 3.85 ms), block-sum strips XOR-swizzled by row against the scatter's 4-way bank conflicts (3.99 vs 3.92)
+#endif
 
 template <int D> struct HxCfg;
 template <> struct HxCfg<128> { static constexpr int BN = 216, MTC = 3; };   // 159 KB LDS: 1 workgroup/CU
@@ -500,23 +505,24 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
             for (int c = 0; c < CPL; ++c) ps[(size_t)v * D + col[c]] = acc_lds[v * D + lane * CPL + c];
         return;
     }
+    // Rows v0, v0 + NWV, ... of one batch: their global reads first, then the arithmetic.
     constexpr int RB = 4;
-    for (int v0 = w; v0 < nrows; v0 += NWV * RB) {
-        float x[RB][CPL], inv[RB];
+    auto load_batch = [&](int v0, float (&x)[RB][CPL], float (&inv)[RB]) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int v = v0 + rb * NWV;
-            const int vc = v < nrows ? v : v0;
-            const int64_t node = node0 + vc;
+            const int64_t node = node0 + (v < nrows ? v : nrows - 1);
             const int deg = indeg[node];
             inv[rb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + col[c]];
         }
+    };
+    auto finish_batch = [&](int v0, float (&x)[RB][CPL], const float (&inv)[RB]) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int v = v0 + rb * NWV;
-            const int vc = v < nrows ? v : v0;
+            const int vc = v < nrows ? v : nrows - 1;
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
@@ -558,6 +564,13 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
                 }
             }
         }
+    };
+    // (Issuing the next batch's reads before this batch's arithmetic was measured on one box against this loop: 3.88
+    // vs 3.85 ms per launch — the tail is not waiting for memory.)
+    for (int v0 = w; v0 < nrows; v0 += NWV * RB) {
+        float x[RB][CPL], inv[RB];
+        load_batch(v0, x, inv);
+        finish_batch(v0, x, inv);
     }
 #ifdef GHF_STAMPS
     HX_STAMP(6);                                        // drain + tail
