@@ -79,7 +79,9 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #ifndef GHF_OPT
 #define GHF_OPT 0            // A/B switches (GHF_VARIANT=opt<mask>, same results; tools/ab.sh): none at the moment.
                              // Tried this way and measured slower on one box: next tail batch's reads issued early (3.88 vs
-                             // 3.85 ms), block-sum strips XOR-swizzled by row against the scatter's 4-way bank conflicts (3.99 vs 3.92)
+                             // 3.85 ms), block-sum strips XOR-swizzled by row against the scatter's 4-way bank conflicts (3.99 vs 3.92),
+                             // s_setprio 3 for the consumers (3.85 vs 3.85) or the producers (3.96), ds_add_f32 per value
+                             // instead of segment sum + read-add-write (12.3 ms)
 #endif
 
 template <int D> struct HxCfg;
