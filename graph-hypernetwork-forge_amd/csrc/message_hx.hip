@@ -69,7 +69,8 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #endif
 
 // Compile-time ablations (GHF_VARIANT=exp<mask>, timing only, wrong results): 1 no B refills, 2 no gathers, 4 no main
-// MFMAs, 8 no scatter, 16 gather one hot row, 32 one relation's weights, 64 no segment-sum MFMAs, 128 no LDS read-add-write
+// MFMAs, 8 no scatter (also lets the compiler drop the MFMAs: use 192), 16 gather one hot row, 32 one relation's weights,
+// 64 no segment-sum MFMAs, 128 no LDS read-add-write, 256 no tail
 #ifndef GHF_EXP
 #define GHF_EXP 0
 #endif
@@ -79,7 +80,8 @@ __device__ unsigned long long ghf_hx_stamp_buf[8192 * 8 * 8];
 #ifndef GHF_OPT
 #define GHF_OPT 0            // A/B switches (GHF_VARIANT=opt<mask>, same results; tools/ab.sh): none at the moment.
                              // Tried this way and measured slower on one box: next tail batch's reads issued early (3.88 vs
-                             // 3.85 ms), block-sum strips XOR-swizzled by row against the scatter's 4-way bank conflicts (3.99 vs 3.92),
+                             // 3.85 ms: see RB), adjacent columns per lane in the tail so that rows move as contiguous 512-byte runs (3.84 vs
+                             // 3.82), A fragments read 3 positions ahead instead of 2 (3.86 vs 3.87), block-sum strips XOR-swizzled by row against the scatter's 4-way bank conflicts (3.99 vs 3.92),
                              // s_setprio 3 for the consumers (3.85 vs 3.85) or the producers (3.96), ds_add_f32 per value
                              // instead of segment sum + read-add-write (12.3 ms)
 #endif
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     }
 
     // ---- fused tail: one wave per destination row, RB rows in flight -----------------------------------------
+    if (GHF_EXP & 256) return;                              // (timing only: no tail — it costs 0.43 of 4.1 ms)
     constexpr int CPL = D / 64;
     // LDS position lane*CPL + c of a row of the sums holds output column col[c] (see the scatter): the lane's two
     // positions are columns o and o + 16.
@@ -508,7 +511,10 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
         return;
     }
     // Rows v0, v0 + NWV, ... of one batch: their global reads first, then the arithmetic.
-    constexpr int RB = 4;
+    // RB = 14: a wave's 27 rows in two batches.  A batch is one memory round trip plus the wait for the previous
+    // batch's stores (vmcnt retires in order), so fewer, larger batches: RB 4 -> 9 -> 14 measured 3.85 -> 3.75 ->
+    // 3.72 ms per launch on one box, 27 the same as 14.
+    constexpr int RB = 14;
     auto load_batch = [&](int v0, float (&x)[RB][CPL], float (&inv)[RB]) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
