@@ -182,3 +182,20 @@ def test_synth_is_deterministic_and_well_distributed():
     assert synth.raw_u64(1003, "src", 2).tolist() == [int(x) for x in synth.raw_u64(1003, "src", 2)]
     assert cases.params_digest(cases.MODELS["small"].params()) == str(
         np.load(os.path.join(cases.GOLDEN_DIR, "g2_toy.npz"))["params_sha256"])
+
+
+def test_header_is_plain_c_and_binds_from_c(tmp_path):
+    """include/ghf.h compiles as C99 (-Wall -Werror) and a C program drives the library through dlopen: the boundary is a
+    C ABI, not a Python extension (tests/c/abi_smoke.c; host-side entry points only, no GPU needed)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(os.path.dirname(__file__), "c", "abi_smoke.c")
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I", _build.INCLUDE, src, "-o", exe, "-ldl"],
+                   check=True, capture_output=True, text=True)
+    _native.load()                                                  # builds the library if it is missing
+    out = subprocess.run([exe, _native.lib_path()], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.strip() == f"ok {_native.ABI_VERSION}"
