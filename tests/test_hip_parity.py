@@ -710,6 +710,32 @@ def test_captured_hip_graph_replays_the_forward(name):
         graphed.replay(x2[:-1])
 
 
+def test_the_binding_shown_in_integration_md_runs():
+    """INTEGRATION.md §2 is executable: its three code blocks, pasted onto modules that hold the reference's parameters
+    under the reference's attribute names, reproduce the golden outputs through the C ABI alone."""
+    import re
+    import torch.nn as nn
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    binding = [b for b in blocks if "_ghf.py" in b.splitlines()[0]][0]
+    fwd = [b for b in blocks if b.lstrip().startswith("# graph_hypernetwork_forge/models/hypergnn.py")][0]
+    gen = [b for b in blocks if b.lstrip().startswith("# graph_hypernetwork_forge/models/weight_generator.py")][0]
+    ns = {"nn": nn, "torch": torch}
+    exec(binding.replace('"libghf_hip.so"', repr(_native.lib_path())), ns)
+    exec(fwd, ns)
+    exec(gen, ns)
+    for name in ("g2_toy", "g3_mid32", "g6_c3"):
+        (case,) = cases.graph_cases(only=[name])
+        model = make_model(cases.MODELS[case.model])
+        for g in model.weight_generators:
+            g.generate_into = ns["generate_into"].__get__(g)
+        with torch.no_grad():
+            out = ns["forward"](model, torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV),
+                                case.edge_texts)
+            ref = model(torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV), case.edge_texts)
+        assert_close(out.cpu().numpy(), ref.cpu().numpy(), f"INTEGRATION.md binding, {name}")
+
+
 def test_row_range_only_touches_its_rows(kernel):
     d, N, E, R = 128, 2000, 20000, 16
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=5, kind="uniform")
