@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU): many small random graphs / shapes through the product forward and backward against
-the oracle.  Not part of the test suite (minutes of oracle time); run when kernels change:
-    python tools/fuzz_parity.py --cases 60 --seed 1"""
+the oracle.  Lives under tests/ (only tests may use the oracle) but is not collected by pytest (minutes of oracle time);
+run it when kernels change:
+    python tests/fuzz_parity.py --cases 60 --seed 1"""
 from __future__ import annotations
 
 import argparse
@@ -10,7 +11,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 import numpy as np
