@@ -86,9 +86,9 @@ class NativeOps:
     def input_proj(self, model, x_rows: torch.Tensor, out_rows: torch.Tensor) -> None:
         _native.input_proj_fwd(x_rows, model.input_proj.weight.detach(), model.input_proj.bias.detach(), out=out_rows)
 
-    def all_weights(self, model, text_embs, plan):
+    def all_weights(self, model, text_embs, plan, after=None):
         """([weights of layer l], [event l] or None): every layer's generation on a side stream (HyperGNN.generate_all)."""
-        return model.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= model.SIDE_STREAM_MIN_EDGES // 8)
+        return model.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= model.SIDE_STREAM_MIN_EDGES // 8, after=after)
 
     def split_rows(self, plan, h):
         """What the message kernel gathers: h itself, or its rows cut into 16-bit pieces."""
@@ -234,9 +234,9 @@ class ShardedHyperGNN:
         h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
         h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
-        all_w, ready = self.ops.all_weights(model, text_embs, plan)
         if self.ops.exchanges_split(plan):
-            return self._forward_split(node_features, plan, spec, all_w, ready, h, h_next)
+            return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
+        all_w, ready = self.ops.all_weights(model, text_embs, plan)
         self._run_chunked(h, spec, lambda lo, hi: self.ops.input_proj(model, node_features[lo:hi], h[lo:hi]))
         for l in range(model.num_layers):
             if ready is not None and ready[l] is not None:
@@ -249,7 +249,7 @@ class ShardedHyperGNN:
             h, h_next = h_next, h
         return h[:N]
 
-    def _forward_split(self, node_features, plan, spec, all_w, ready, h, h_next) -> torch.Tensor:
+    def _forward_split(self, node_features, plan, spec, text_embs, h, h_next) -> torch.Tensor:
         """Layers whose kernel gathers pre-split rows: a rank keeps fp32 h for its own rows only (the residual input of
         the next layer) and the ranks exchange the split rows their fused tails wrote; fp32 rows travel once, at the end."""
         model, ops = self.model, self.ops
@@ -259,7 +259,14 @@ class ShardedHyperGNN:
         def project(lo, hi):
             ops.input_proj(model, node_features[lo:hi], h[lo:hi])
             ops.split_range(plan, h[:N], hs, lo, hi)
+        te_done = None
+        if node_features.is_cuda:
+            te_done = torch.cuda.Event()
+            te_done.record(torch.cuda.current_stream(device))
         self._run_chunked(ops.split_parts(plan, hs, N, d), spec, project)
+        # enqueued after the projection step so that its kernels are not queued behind the generators' on a shared
+        # hardware queue; the side stream itself only waits for the text embeddings
+        all_w, ready = ops.all_weights(model, text_embs, plan, after=te_done)
         last = model.num_layers - 1
         for l in range(model.num_layers):
             if ready is not None and ready[l] is not None:

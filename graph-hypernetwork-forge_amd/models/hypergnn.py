@@ -218,7 +218,7 @@ class HyperGNN(nn.Module):
             h = MessageLayerFn.apply(h, W_msg, W_self, bias, norm.weight, norm.bias, norm.eps, plan.train)
         return h
 
-    def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True):
+    def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True, after=None):
         """([weights of layer l], [event l or None]): every layer's weight generation.  The generated weights depend on
         the relation strings only, so on large graphs their ~0.13 ms of small latency-bound kernels per layer are
         launched on a side stream and run in the shadow of the previous layers (C3: 13.0 -> 12.7 ms per forward); the
@@ -231,7 +231,10 @@ class HyperGNN(nn.Module):
         if self._wg_stream is None or self._wg_stream.device != dev:
             self._wg_stream = torch.cuda.Stream(device=dev)
         side = self._wg_stream
-        side.wait_stream(main)                                        # text_embs, and the previous call's readers
+        if after is not None:
+            side.wait_event(after)                                    # an event recorded once text_embs was enqueued
+        else:
+            side.wait_stream(main)                                    # text_embs, and the previous call's readers
         weights, ready = [], []
         try:
             torch.cuda.set_stream(side)
@@ -258,14 +261,18 @@ class HyperGNN(nn.Module):
         text_embs = self.text_encoder(plan.unique_texts, device)     # [U, text_dim]
         # the 16-bit-piece kernels gather rows already cut into pieces: the input projection emits them for the first
         # layer, every layer's tail for the next
-        weights, ready = self.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= self.SIDE_STREAM_MIN_EDGES)
         main = torch.cuda.current_stream(device)
+        te_done = torch.cuda.Event()
+        te_done.record(main)
         split = plan.wlayout in _native.SPLIT_LAYOUTS
         hs = _native.alloc_split(x.size(0), self.hidden_dim, plan.wlayout, device) if split else None
         hs_next = torch.empty_like(hs) if split else None
         h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach(), h_split=hs,
                                    split_layout=plan.wlayout if split else 0)
         h_next = torch.empty_like(h)
+        # (enqueued after the input projection: streams can share a hardware queue, and packets queue in host order)
+        weights, ready = self.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= self.SIDE_STREAM_MIN_EDGES,
+                                           after=te_done)
         lo, hi = plan.row_lo, (plan.row_hi or plan.N)
         last = len(self.weight_generators) - 1
         for l, norm in enumerate(self.layer_norms):

@@ -47,7 +47,7 @@ class OracleOps:
     def input_proj(self, model, x_rows, out_rows):
         out_rows.copy_(torch.relu(x_rows @ model.input_proj.weight.t() + model.input_proj.bias))
 
-    def all_weights(self, model, text_embs, plan):
+    def all_weights(self, model, text_embs, plan, after=None):
         d = model.hidden_dim
         return [O.weight_generator(self._params(model), f"weight_generators.{l}.", text_embs, d, d)
                 for l in range(model.num_layers)], None
