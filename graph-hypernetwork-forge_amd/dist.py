@@ -4,7 +4,7 @@ The path shards by DESTINATION node: a rank owns every in-edge of its rows, so e
 owned by exactly one rank, the per-destination sums never cross ranks and the fused tail
 stays local.  The one real exchange step per layer is making the new h visible everywhere:
 an all-gather of rows over xGMI (half the bytes of the all-reduce an edge-range
-partition would need — SURVEY.md §8e).  What travels is what the next layer's kernel gathers:
+partition would need — SURVEY.md §8e).  The input projection is not exchanged: every rank computes it for all rows.  What travels is what the next layer's kernel gathers:
 for the default d = 128 kernel the rows already cut into their two fp16 pieces plus the row
 scales (written by the layer kernel's fused tail, 4 d + 4 bytes per row, the same volume as
 fp32), so no rank ever re-splits the full h; fp32 rows travel only after the last layer, and
@@ -16,8 +16,8 @@ into C chunks of G*S rows, and inside chunk c rank g owns rows [(c*G+g)*S, (c*G+
     for c in chunks:  launch the message kernel on my rows of chunk c          (compute stream)
                       all-gather chunk c in place: a contiguous [G*S, d] slice   (comm stream)
 so the gather of chunk c travels while chunk c+1 computes, and only the last chunk's gather
-is exposed.  The input projection is sharded the same way; weight generation (0.5 GFLOP) is
-recomputed on every rank instead of broadcast.
+is exposed.  Weight generation (0.5 GFLOP) and the input projection (33 GFLOP) are recomputed on every rank
+instead of exchanged.
 
 The compute steps come from an `ops` object so that the sharding / exchange logic can be
 exercised on CPU with gloo (tests/test_dist_gloo.py injects the oracle there); the product
@@ -83,8 +83,12 @@ class NativeOps:
     def text_embs(self, model, unique: Sequence[str], device) -> torch.Tensor:
         return model.text_encoder(unique, device)
 
-    def input_proj(self, model, x_rows: torch.Tensor, out_rows: torch.Tensor) -> None:
-        _native.input_proj_fwd(x_rows, model.input_proj.weight.detach(), model.input_proj.bias.detach(), out=out_rows)
+    def input_proj(self, model, x: torch.Tensor, out: torch.Tensor, h_split, plan) -> None:
+        """h0 for ALL rows on every rank (with the split form the first layer gathers, when the kernel wants one):
+        0.7 ms of replicated compute at C3 instead of an exchange of N rows, which costs more on every fabric size
+        (one xGMI link moves 258 MB in 3.4 ms at 2 GPUs; seven move 451 MB in >= 0.84 ms at 8)."""
+        _native.input_proj_fwd(x, model.input_proj.weight.detach(), model.input_proj.bias.detach(), out=out,
+                               h_split=h_split, split_layout=plan.wlayout if h_split is not None else 0)
 
     def all_weights(self, model, text_embs, plan, after=None):
         """([weights of layer l], [event l] or None): every layer's generation on a side stream (HyperGNN.generate_all)."""
@@ -105,9 +109,6 @@ class NativeOps:
         """The row-indexed regions of a split buffer as [N, bytes] views: what the exchange moves."""
         b = hs.view(torch.uint8)
         return [b[: N * 4 * d].view(N, 4 * d), b[N * 4 * d: N * 4 * d + 4 * N].view(N, 4)]
-
-    def split_range(self, plan, h, hs, lo: int, hi: int) -> None:
-        _native.split_rows(h, plan.wlayout, out=hs, row0=lo, rows=hi - lo)
 
     def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int, h_split_out=None) -> None:
         norm = model.layer_norms[l]
@@ -237,7 +238,7 @@ class ShardedHyperGNN:
         if self.ops.exchanges_split(plan):
             return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
         all_w, ready = self.ops.all_weights(model, text_embs, plan)
-        self._run_chunked(h, spec, lambda lo, hi: self.ops.input_proj(model, node_features[lo:hi], h[lo:hi]))
+        self.ops.input_proj(model, node_features, h[:N], None, plan)
         for l in range(model.num_layers):
             if ready is not None and ready[l] is not None:
                 torch.cuda.current_stream(device).wait_event(ready[l])
@@ -256,16 +257,13 @@ class ShardedHyperGNN:
         N, d, device = node_features.size(0), model.hidden_dim, node_features.device
         hs, hs_next = ops.alloc_split(plan, N, d, device), ops.alloc_split(plan, N, d, device)
 
-        def project(lo, hi):
-            ops.input_proj(model, node_features[lo:hi], h[lo:hi])
-            ops.split_range(plan, h[:N], hs, lo, hi)
         te_done = None
         if node_features.is_cuda:
             te_done = torch.cuda.Event()
             te_done.record(torch.cuda.current_stream(device))
-        self._run_chunked(ops.split_parts(plan, hs, N, d), spec, project)
-        # enqueued after the projection step so that its kernels are not queued behind the generators' on a shared
-        # hardware queue; the side stream itself only waits for the text embeddings
+        ops.input_proj(model, node_features, h[:N], hs, plan)
+        # enqueued after the projection so that its kernel is not queued behind the generators' on a shared hardware
+        # queue; the side stream itself only waits for the text embeddings
         all_w, ready = ops.all_weights(model, text_embs, plan, after=te_done)
         last = model.num_layers - 1
         for l in range(model.num_layers):

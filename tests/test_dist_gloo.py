@@ -44,8 +44,10 @@ class OracleOps:
     def text_embs(self, model, unique, device):
         return O.text_encode(self._params(model), unique)
 
-    def input_proj(self, model, x_rows, out_rows):
-        out_rows.copy_(torch.relu(x_rows @ model.input_proj.weight.t() + model.input_proj.bias))
+    def input_proj(self, model, x, out, h_split, plan):
+        out.copy_(torch.relu(x @ model.input_proj.weight.t() + model.input_proj.bias))
+        if h_split is not None:
+            self.split_range(plan, out, h_split, 0, out.size(0))
 
     def all_weights(self, model, text_embs, plan, after=None):
         d = model.hidden_dim
