@@ -41,20 +41,31 @@ __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __res
             const float bv = bias[16 * t + c16];         // D column = lane & 15
             acc[m][t] = (f32x4){bv, bv, bv, bv};
         }
+    // x fragments one 16-wide k-slice ahead, W fragments one column tile ahead: the MFMAs of a tile (256 cycles) cover
+    // both loads (W_in is L1/L2 resident; x streams from HBM once)
     const int NJ = F >> 4;
-    for (int j = 0; j < NJ; ++j) {
-        f32x4 a[IP_MT];
+    const float* __restrict__ wrow = W + (size_t)c16 * F + 4 * q;
+    f32x4 a[IP_MT], an[IP_MT];
 #pragma unroll
-        for (int m = 0; m < IP_MT; ++m) a[m] = *(const f32x4*)(arow[m] + 16 * j);
+    for (int m = 0; m < IP_MT; ++m) a[m] = *(const f32x4*)(arow[m]);
+    f32x4 b = *(const f32x4*)(wrow);
+    for (int j = 0; j < NJ; ++j) {
+        const int jn = j + 1 < NJ ? j + 1 : j;            // (the last slice is read twice: no branch around the loads)
+#pragma unroll
+        for (int m = 0; m < IP_MT; ++m) an[m] = *(const f32x4*)(arow[m] + 16 * jn);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x4 b = *(const f32x4*)(W + (size_t)(16 * t + c16) * F + 16 * j + 4 * q);
+            const f32x4 bn = t + 1 < NT ? *(const f32x4*)(wrow + (size_t)16 * (t + 1) * F + 16 * j)
+                                        : *(const f32x4*)(wrow + 16 * jn);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int m = 0; m < IP_MT; ++m)
                     acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m][t], 0, 0, 0);
+            b = bn;
         }
+#pragma unroll
+        for (int m = 0; m < IP_MT; ++m) a[m] = an[m];
     }
     // D: lane holds rows 4q + reg, column 16t + c16
 #pragma unroll
