@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
@@ -59,6 +59,9 @@ SIGNATURES = {
     "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ghf_relu_mask": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "ghf_message_rs_supported": (_i32, [_i32]),
+    "ghf_edge_transform_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
     "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
@@ -302,6 +305,33 @@ def score_pairs_fwd(a: torch.Tensor, b: torch.Tensor, ia: Optional[torch.Tensor]
     _check(load().ghf_score_pairs_fwd(_ptr(a), _ptr(b), _ptr(ia), _ptr(ib), a.size(0), b.size(0), n, a.size(1), _ptr(out),
                                       _stream()), "ghf_score_pairs_fwd")
     return out
+
+
+# ---- wide hidden sizes: relation-stationary layer (include/ghf.h, csrc/message_rs.hip) ---------------------------
+
+def rs_supported(d: int) -> bool:
+    return bool(load().ghf_message_rs_supported(d)) and os.environ.get("GHF_KERNEL") != "generic"
+
+
+def edge_transform_fwd(h: torch.Tensor, rs, WmT: torch.Tensor, WsT: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """Pass 1: per-edge results into Y [E, d] at the edges' destination-order positions (rs: plan.RsPlan)."""
+    h = _req(h, torch.float32, "h")
+    N, d = h.shape
+    _check(load().ghf_edge_transform_fwd(_ptr(h), N, d, _ptr(rs.src), _ptr(rs.dst), _ptr(rs.ypos), _ptr(rs.slice_tab),
+                                         rs.slice_tab.size(0), _ptr(_req(WmT, torch.float32, "WmT")),
+                                         _ptr(_req(WsT, torch.float32, "WsT")), _ptr(_req(bias, torch.float32, "bias")),
+                                         _ptr(Y), _stream()), "ghf_edge_transform_fwd")
+    return Y
+
+
+def segment_tail_fwd(Y: torch.Tensor, rs, h: Optional[torch.Tensor], ln_gamma, ln_beta, ln_eps: float, h_out: torch.Tensor,
+                     row0: int = 0, rows: Optional[int] = None, flags: int = 0) -> torch.Tensor:
+    """Pass 2: destination sums of Y, mean and tail for rows [row0, row0+rows)."""
+    N, d = h_out.shape
+    rows = N - row0 if rows is None else rows
+    _check(load().ghf_segment_tail_fwd(_ptr(Y), _ptr(rs.off), _ptr(h), _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows,
+                                       d, _ptr(h_out), flags, _stream()), "ghf_segment_tail_fwd")
+    return h_out
 
 
 # ---- backward pieces (include/ghf.h: "backward of the path") ----------------------------------------------------

@@ -193,6 +193,22 @@ int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, c
     return launch_group_outer(A, ia, da, B, ib, db, gstart, gend, ngroups, C, accumulate, (hipStream_t)stream);
 }
 
+int ghf_message_rs_supported(int d) { return message_rs_supported(d); }
+
+int ghf_edge_transform_fwd(const float* h, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
+                           const int64_t* slice_tab, int64_t nslices, const float* WmT, const float* WsT, const float* bias,
+                           float* Y, void* stream) {
+    GHF_REQUIRE(h && src && dst && ypos && slice_tab && WmT && WsT && bias && Y, "edge_transform_fwd: null pointer argument");
+    return launch_edge_transform(h, N, d, src, dst, ypos, slice_tab, nslices, WmT, WsT, bias, Y, (hipStream_t)stream);
+}
+
+int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const float* h, const float* ln_gamma, const float* ln_beta,
+                         float ln_eps, int64_t row0, int64_t rows, int d, float* h_out, int flags, void* stream) {
+    GHF_REQUIRE(Y && off && h_out, "segment_tail_fwd: null pointer argument");
+    GHF_REQUIRE((flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM)) || (h && ln_gamma && ln_beta), "segment_tail_fwd: tail inputs missing");
+    return launch_segment_tail(Y, off, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, flags, (hipStream_t)stream);
+}
+
 int ghf_edge_outer_supported(int d) { return edge_outer_supported(d); }
 
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,

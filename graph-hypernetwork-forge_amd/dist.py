@@ -34,7 +34,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native
-from .plan import GraphPlan, build_plan, relation_ids
+from .plan import GraphPlan, build_plan, build_rs, relation_ids
 
 
 @dataclass
@@ -110,9 +110,25 @@ class NativeOps:
         b = hs.view(torch.uint8)
         return [b[: N * 4 * d].view(N, 4 * d), b[N * 4 * d: N * 4 * d + 4 * N].view(N, 4)]
 
+    def layer_begin(self, model, l: int, weights, h, plan) -> None:
+        """Once per layer, before its chunks.  Wide rows (csrc/message_rs.hip): pass 1 over all of this rank's edges —
+        it runs in relation order, not by destination chunk; the chunks then only do pass 2 on their rows."""
+        if plan.block_nodes == 1 and _native.rs_supported(h.size(1)) and plan.E > 0:
+            if plan.rs is None:
+                plan.rs = build_rs(plan)
+            W_msg, W_self, bias = weights
+            _native.edge_transform_fwd(h, plan.rs, _native.transpose_batched(W_msg), _native.transpose_batched(W_self), bias,
+                                       plan.rs.scratch(plan.E, h.size(1), h.device))
+
     def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int, h_split_out=None) -> None:
         norm = model.layer_norms[l]
         W, W_self, bias = weights
+        if plan.block_nodes == 1 and _native.rs_supported(h.size(1)):
+            if plan.rs is None:
+                plan.rs = build_rs(plan)
+            _native.segment_tail_fwd(plan.rs.scratch(plan.E, h.size(1), h.device), plan.rs, h, norm.weight.detach(),
+                                     norm.bias.detach(), norm.eps, h_out, row0=lo, rows=hi - lo)
+            return
         _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(), norm.bias.detach(),
                                   norm.eps, h_out, row0=lo, rows=hi - lo, h_split=h_split, h_split_out=h_split_out)
 
@@ -244,6 +260,7 @@ class ShardedHyperGNN:
                 torch.cuda.current_stream(device).wait_event(ready[l])
             weights = all_w[l]
             src, dst = h, h_next
+            self.ops.layer_begin(model, l, weights, src[:N], plan)
             src_split = self.ops.split_rows(plan, src[:N])          # all rows are in place after the previous exchange
             self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], src_split, plan,
                                                                             dst[:N], lo, hi))

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native
-from ..plan import GraphPlan, PlanCache, build_plan, relation_ids
+from ..plan import GraphPlan, PlanCache, build_plan, build_rs, relation_ids
 from .weight_generator import WeightGenerator, require_inference, wants_grad
 
 
@@ -258,6 +258,8 @@ class HyperGNN(nn.Module):
         require_inference(self, node_features, what=".forward_planned")
         device = node_features.device
         x = node_features if node_features.dtype == torch.float32 else node_features.float()
+        if plan.block_nodes == 1 and _native.rs_supported(self.hidden_dim):
+            return self._forward_wide(x, plan, exchange)
         text_embs = self.text_encoder(plan.unique_texts, device)     # [U, text_dim]
         # the 16-bit-piece kernels gather rows already cut into pieces: the input projection emits them for the first
         # layer, every layer's tail for the next
@@ -289,6 +291,28 @@ class HyperGNN(nn.Module):
                     _native.split_rows(h_next, plan.wlayout, out=hs_next)
             h, h_next = h_next, h
             hs, hs_next = hs_next, hs
+        return h
+
+    def _forward_wide(self, x: torch.Tensor, plan: GraphPlan, exchange=None) -> torch.Tensor:
+        """Wide rows (d % 128 == 0, d >= 256: BASELINE config 5): the relation-stationary layer of csrc/message_rs.hip —
+        per-edge results in relation order with the weights read once per 128 edges, then destination sums + tail."""
+        device = x.device
+        if plan.rs is None:
+            plan.rs = build_rs(plan)
+        rs = plan.rs
+        text_embs = self.text_encoder(plan.unique_texts, device)
+        h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach())
+        h_next = torch.empty_like(h)
+        Y = rs.scratch(plan.E, self.hidden_dim, device)
+        lo, hi = plan.row_lo, (plan.row_hi or plan.N)
+        for gen, norm in zip(self.weight_generators, self.layer_norms):
+            W_msg, W_self, bias = gen.generate(text_embs, _native.WLAYOUT_NATURAL)
+            if plan.E > 0:
+                _native.edge_transform_fwd(h, rs, _native.transpose_batched(W_msg), _native.transpose_batched(W_self), bias, Y)
+            _native.segment_tail_fwd(Y, rs, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo)
+            if exchange is not None:
+                exchange(h_next)
+            h, h_next = h_next, h
         return h
 
     # -- reference-internal seam kept for API parity (reference :160-230) ---------------------

@@ -31,6 +31,50 @@ def relation_ids(edge_texts: Sequence[str]) -> Tuple[List[str], np.ndarray]:
 
 
 @dataclass
+class RsPlan:
+    """What the relation-stationary layer (csrc/message_rs.hip, wide hidden sizes) reads besides the CSR plan."""
+    src: torch.Tensor        # [E] int64, edges in relation order (destination ascending inside a relation)
+    dst: torch.Tensor        # [E] int64
+    ypos: torch.Tensor       # [E] int64: the edge's position in destination order = its row of the per-edge results
+    slice_tab: torch.Tensor  # [S, 3] int64 (relation, first edge, end edge): tiles of at most RS_TILE edges
+    off: torch.Tensor        # [N+1] int64: a destination's rows of the per-edge results
+    _Y: Optional[torch.Tensor] = None
+
+    def scratch(self, E: int, d: int, device) -> torch.Tensor:
+        if self._Y is None or self._Y.numel() < E * d:
+            self._Y = torch.empty(max(E, 1) * d, dtype=torch.float32, device=device)
+        return self._Y
+
+
+RS_TILE = 128
+SRC_MASK = 0x0FFFFFFF
+
+
+def build_rs(plan: "GraphPlan") -> RsPlan:
+    """From a CSR plan (block_nodes == 1: edges sorted by key = dst * R + relation): the same edges grouped by relation.
+    One device sort and one host sync per plan."""
+    if plan.block_nodes != 1:
+        raise ValueError("the relation-stationary layer runs on CSR plans (block_nodes == 1)")
+    dev, R, N, E = plan.sorted_key.device, plan.R, plan.N, plan.E
+    off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(plan.indeg.to(torch.int64), 0)
+    if E == 0:
+        z = torch.zeros(1, dtype=torch.int64, device=dev)
+        return RsPlan(src=z, dst=z, ypos=z, slice_tab=torch.zeros(0, 3, dtype=torch.int64, device=dev), off=off)
+    key = plan.sorted_key[:E].to(torch.int64) & 0xFFFFFFFF
+    dst, rel = torch.div(key, R, rounding_mode="floor"), key % R
+    src = plan.sorted_src[:E].to(torch.int64) & SRC_MASK
+    perm = torch.sort(rel, stable=True).indices
+    counts = torch.bincount(rel, minlength=R).cpu().tolist()
+    tab, e = [], 0
+    for r, c in enumerate(counts):
+        tab += [(r, a, min(a + RS_TILE, e + c)) for a in range(e, e + c, RS_TILE)]
+        e += c
+    return RsPlan(src=src.index_select(0, perm).contiguous(), dst=dst.index_select(0, perm).contiguous(), ypos=perm.contiguous(),
+                  slice_tab=torch.tensor(tab, dtype=torch.int64).to(dev), off=off)
+
+
+@dataclass
 class GraphPlan:
     N: int
     E: int
@@ -54,6 +98,7 @@ class GraphPlan:
     row_lo: int = 0                # destination rows this plan covers (multi-GPU shards)
     row_hi: int = 0
     train: Optional[object] = None  # autograd.TrainPlan, built by the first forward that records gradients
+    rs: Optional[RsPlan] = None     # relation-stationary extras, built by the first wide-row forward
 
     def bytes(self) -> int:
         ts = (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg, self.chunk_tab, self.blk_chunk_off,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 7
+#define GHF_ABI_VERSION 8
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -166,6 +166,22 @@ size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout);
 int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
                  const float* ln_gamma, const float* ln_beta, float ln_eps,
                  int64_t row0, int64_t rows, int d, float* h_out, void* stream);
+
+/* ---- wide hidden sizes: the relation-stationary message layer (csrc/message_rs.hip) ---------------------------------
+ * For d % 128 == 0, 256 <= d <= 1024 (ghf_message_rs_supported; BASELINE config 5).  Same statement as
+ * ghf_message_layer_fwd, in two passes over a CSR plan (block_nodes == 1):
+ *   ghf_edge_transform_fwd: Y[ypos[k]] = h[src[k]] W_msg[r] + bias[r] + h[dst[k]] W_self[r] for the edges k in RELATION order
+ *       (src / dst / ypos [E] int64: the edge's ends and its position in destination order); slice_tab [nslices][3] int64 =
+ *       (relation, first edge, end edge) cuts every relation's range into tiles of at most 128 edges; WmT / WsT [R][d][d]
+ *       are the weights TRANSPOSED ([r][out][in], ghf_transpose_batched of the natural layout); Y [E][d] fp32 scratch.
+ *   ghf_segment_tail_fwd: rows [row0, row0+rows): out_v = sum(Y[off[v] .. off[v+1])) / max(indeg, 1), then the tail of
+ *       ghf_tail_fwd (flags: GHF_FLAG_NO_TAIL / GHF_FLAG_RAW_SUM as for the message layer); off [N+1] int64. */
+int ghf_message_rs_supported(int d);
+int ghf_edge_transform_fwd(const float* h, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
+                           const int64_t* slice_tab, int64_t nslices, const float* WmT, const float* WsT, const float* bias,
+                           float* Y, void* stream);
+int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const float* h, const float* ln_gamma, const float* ln_beta,
+                         float ln_eps, int64_t row0, int64_t rows, int d, float* h_out, int flags, void* stream);
 
 /* ---- backward of the path (the reference trains through it with autograd: demo.py:79-101) ----------
  * With out_v = (1/c_v) sum_e(h_u Wm[r] + b[r] + h_v Ws[r]), x = relu(out + h), h' = LayerNorm(x), g' = dL/dh':

@@ -57,6 +57,9 @@ class OracleOps:
     def split_rows(self, plan, h):
         return None
 
+    def layer_begin(self, model, l, weights, h, plan):
+        pass
+
     # the split exchange of dist.NativeOps with a stand-in split form: N rows of the fp32 bytes, then N float ones
     def exchanges_split(self, plan):
         return self.split

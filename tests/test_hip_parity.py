@@ -710,6 +710,76 @@ def test_captured_hip_graph_replays_the_forward(name):
         graphed.replay(x2[:-1])
 
 
+@pytest.mark.parametrize("d,N,E,R,kind", [(256, 700, 9000, 9, "uniform"), (256, 300, 20000, 5, "powerlaw"), (384, 90, 60, 7, "uniform"),
+                                          (256, 1500, 1200, 40, "powerlaw")])
+def test_wide_rows_layer_matches_oracle(d, N, E, R, kind):
+    """csrc/message_rs.hip (d % 128 == 0, d >= 256): per-edge results in relation order + destination sums + tail against
+    the oracle and against the generic kernel; tiles shorter than 128 edges, relations without edges, hubs, isolated rows,
+    row ranges, NO_TAIL and RAW_SUM."""
+    from graph_hypernetwork_forge_amd.plan import build_rs
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=11 + d + R, kind=kind)
+    rel = np.where(rel == R - 1, 0, rel)                                # the last relation stays empty
+    t = lambda a: torch.from_numpy(a).to(DEV)                           # noqa: E731
+    th = torch.from_numpy
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    assert plan.block_nodes == 1 and _native.rs_supported(d)
+    rs = build_rs(plan)
+    assert rs.slice_tab.size(0) >= E // 128 and int(rs.off[-1]) == E
+    Y = torch.full((E, d), float("nan"), device=DEV)
+    WmT, WsT = _native.transpose_batched(t(Wm)), _native.transpose_batched(t(Ws))
+    _native.edge_transform_fwd(t(h), rs, WmT, WsT, t(b), Y)
+    assert bool(torch.isfinite(Y).all()), "every edge's row of the per-edge results is written"
+    agg = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
+    ref = O.layer_tail(agg, th(h), th(gamma), th(beta))
+    out = torch.empty(N, d, device=DEV)
+    _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, out)
+    assert_close(out.cpu().numpy(), ref.numpy(), "wide-row layer")
+    again = torch.empty_like(out)
+    _native.edge_transform_fwd(t(h), rs, WmT, WsT, t(b), Y)
+    _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, again)
+    assert torch.equal(out, again)
+    raw = torch.empty_like(out)
+    _native.segment_tail_fwd(Y, rs, None, None, None, 0.0, raw, flags=_native.GHF_FLAG_NO_TAIL)
+    assert_close(raw.cpu().numpy(), agg.numpy(), "wide-row layer, no tail")
+    part = torch.full_like(out, 7.0)
+    _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, part, row0=N // 3, rows=N // 4)
+    assert torch.equal(part[N // 3: N // 3 + N // 4], out[N // 3: N // 3 + N // 4]) and (part[: N // 3] == 7.0).all()
+    gen = torch.empty_like(out)                                         # the generic kernel on the same plan
+    _native.message_layer_fwd(t(h), plan, t(Wm), t(Ws), t(b), _native.WLAYOUT_NATURAL, t(gamma), t(beta), 1e-5, gen)
+    assert_close(out.cpu().numpy(), gen.cpu().numpy(), "wide-row layer vs generic kernel")
+
+
+def test_wide_rows_forward_and_sharding(monkeypatch):
+    """HyperGNN.forward at hidden 256 takes the relation-stationary layer (and the generic one under GHF_KERNEL=generic);
+    both equal the oracle, and the chunked multi-GPU driver gives the same rows (world-1 NCCL group)."""
+    import torch.distributed as dist
+    from graph_hypernetwork_forge_amd.dist import ShardedHyperGNN
+    d, N, E, R = 256, 1300, 15000, 11
+    g = synth.make_kg(N, E, R, 24, seed=5150, kind="powerlaw")
+    params = synth.hypergnn_params(32, 24, d, 2, seed=9, log_scale=-0.5, randomize_ln=True)
+    model = HyperGNN(32, 24, d, 2).to(DEV).eval()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    x, ei, texts = torch.from_numpy(g.node_features).to(DEV), torch.from_numpy(g.edge_index).to(DEV), g.edge_texts()
+    ref = O.forward(params, g.node_features, g.edge_index, texts, variant="factorised").numpy()
+    with torch.no_grad():
+        out = model(x, ei, texts)
+        assert model.plan_for(ei, texts, N, DEV).rs is not None, "hidden 256 must take the relation-stationary layer"
+        assert_close(out.cpu().numpy(), ref, "hidden 256 forward")
+        monkeypatch.setenv("GHF_KERNEL", "generic")
+        model.clear_plan_cache()
+        assert_close(model(x, ei, texts).cpu().numpy(), ref, "hidden 256 forward, generic kernel")
+        assert model.plan_for(ei, texts, N, DEV).rs is None
+        monkeypatch.delenv("GHF_KERNEL")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29519")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        sharded = ShardedHyperGNN(model, chunks=3)(x, ei, texts)
+        assert_close(sharded.cpu().numpy(), ref, "hidden 256, chunked driver")
+    finally:
+        dist.destroy_process_group()
+
+
 def test_the_binding_shown_in_integration_md_runs():
     """INTEGRATION.md §2 is executable: its three code blocks, pasted onto modules that hold the reference's parameters
     under the reference's attribute names, reproduce the golden outputs through the C ABI alone."""
