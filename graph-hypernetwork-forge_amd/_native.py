@@ -61,7 +61,8 @@ SIGNATURES = {
     "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "ghf_message_rs_supported": (_i32, [_i32]),
     "ghf_edge_transform_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _i32, _vp]),
+    "ghf_segment_partial_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
     "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
@@ -321,6 +322,9 @@ def edge_transform_fwd(h: torch.Tensor, rs, WmT: torch.Tensor, WsT: torch.Tensor
                                          rs.slice_tab.size(0), _ptr(_req(WmT, torch.float32, "WmT")),
                                          _ptr(_req(WsT, torch.float32, "WsT")), _ptr(_req(bias, torch.float32, "bias")),
                                          _ptr(Y), _stream()), "ghf_edge_transform_fwd")
+    if rs.hub_of is not None:                       # hubs: their rows in chunks (fixed order); pass 2 adds the chunks' sums
+        _check(load().ghf_segment_partial_fwd(_ptr(Y), _ptr(rs.hub_chunks), rs.hub_chunks.size(0), d, _ptr(rs.hub_scratch(d)),
+                                              _stream()), "ghf_segment_partial_fwd")
     return Y
 
 
@@ -329,8 +333,10 @@ def segment_tail_fwd(Y: torch.Tensor, rs, h: Optional[torch.Tensor], ln_gamma, l
     """Pass 2: destination sums of Y, mean and tail for rows [row0, row0+rows)."""
     N, d = h_out.shape
     rows = N - row0 if rows is None else rows
-    _check(load().ghf_segment_tail_fwd(_ptr(Y), _ptr(rs.off), _ptr(h), _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows,
-                                       d, _ptr(h_out), flags, _stream()), "ghf_segment_tail_fwd")
+    P = rs.hub_scratch(d) if rs.hub_of is not None else None      # filled by edge_transform_fwd
+    _check(load().ghf_segment_tail_fwd(_ptr(Y), _ptr(rs.off), _ptr(rs.hub_of), _ptr(rs.hub_tab), _ptr(P), _ptr(h), _ptr(ln_gamma),
+                                       _ptr(ln_beta), float(ln_eps), row0, rows, d, _ptr(h_out), flags, _stream()),
+           "ghf_segment_tail_fwd")
     return h_out
 
 

@@ -113,58 +113,98 @@ __global__ __launch_bounds__(256) void edge_transform_kernel(
         }
 }
 
-// Pass 2: out_v = (1/max(indeg,1)) * sum of v's rows of Y (contiguous: off[v] .. off[v+1]), then the tail.  One wave per
-// destination, four rows in flight per lane and column, fixed summation order.
 constexpr int RS_MAX_D = 1024, RS_PER_LANE = RS_MAX_D / 64;
+
+// Hubs (a power-law graph's destinations with more rows than one wave should walk): their rows are cut into chunks
+// (hub_chunks: first row, end row, slot), one workgroup sums a chunk — each wave a quarter, the quarters added in wave
+// order — into P[slot]; pass 2 then sums a hub's slots instead of its rows.  Fixed order throughout.
+__global__ __launch_bounds__(256) void segment_partial_kernel(const float* __restrict__ Y, const int64_t* __restrict__ hub_chunks,
+                                                              int d, float* __restrict__ P) {
+    __shared__ float red[4][RS_MAX_D];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t p0 = hub_chunks[3 * (size_t)blockIdx.x], p1 = hub_chunks[3 * (size_t)blockIdx.x + 1],
+                  slot = hub_chunks[3 * (size_t)blockIdx.x + 2];
+    const int64_t per = (p1 - p0 + 3) / 4;
+    const int64_t a = p0 + w * per, bnd = a + per < p1 ? a + per : p1;
+    for (int o = lane; o < d; o += 64) {
+        const float* __restrict__ p = Y + (size_t)a * d + o;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int64_t j = 0;
+        const int64_t n = bnd - a;
+        for (; j + 4 <= n; j += 4) {
+            t0 += p[(size_t)j * d];
+            t1 += p[(size_t)(j + 1) * d];
+            t2 += p[(size_t)(j + 2) * d];
+            t3 += p[(size_t)(j + 3) * d];
+        }
+        for (; j < n; ++j) t0 += p[(size_t)j * d];
+        red[w][o] = (t0 + t1) + (t2 + t3);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < d; o += 256) P[(size_t)slot * d + o] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+}
+
+// Pass 2: out_v = (1/max(indeg,1)) * sum of v's rows of Y (contiguous: off[v] .. off[v+1]; a hub's slots of P instead),
+// then the tail.  One wave per destination; CPL = d / 64 columns per lane, all of a row's loads issued together and two
+// rows in flight (most destinations of a sharded power-law graph have a handful of rows: the wave's time is the
+// latency of its few loads, so they must not queue behind each other).  Fixed summation order.
+template <int CPL>
 __global__ __launch_bounds__(256) void segment_tail_kernel(
-    const float* __restrict__ Y, const int64_t* __restrict__ off, const float* __restrict__ h, const float* __restrict__ g,
-    const float* __restrict__ b, float eps, int64_t row0, int64_t row_end, int d, float* __restrict__ h_out, int no_tail) {
+    const float* __restrict__ Y, const int64_t* __restrict__ off, const int32_t* __restrict__ hub_of,
+    const int64_t* __restrict__ hub_tab, const float* __restrict__ P, const float* __restrict__ h, const float* __restrict__ g,
+    const float* __restrict__ b, float eps, int64_t row0, int64_t row_end, float* __restrict__ h_out, int no_tail) {
+    constexpr int d = 64 * CPL;
     const int lane = threadIdx.x & 63;
     const int64_t v = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= row_end) return;
-    const int64_t p0 = off[v], p1 = off[v + 1];
-    const int64_t deg = p1 - p0;
-    const float inv = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
-    float x[RS_PER_LANE];
+    int64_t p0 = off[v], p1 = off[v + 1];
+    const int64_t indeg = p1 - p0;
+    float hv[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) hv[c] = no_tail ? 0.f : h[(size_t)v * d + lane + 64 * c];
+    const int hub = hub_of ? hub_of[v] : -1;
+    if (hub >= 0) {                                        // (uniform per wave)
+        p0 = hub_tab[2 * (size_t)hub];
+        p1 = p0 + hub_tab[2 * (size_t)hub + 1];
+        Y = P;
+    }
+    const int64_t deg = p1 - p0;                           // rows to add; the mean divides by the in-degree
+    const float inv = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(indeg > 1 ? indeg : 1);
+    float t0[CPL], t1[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) t0[c] = t1[c] = 0.f;
+    const float* __restrict__ p = Y + (size_t)p0 * d + lane;
+    int64_t j = 0;
+    for (; j + 2 <= deg; j += 2) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            t0[c] += p[(size_t)j * d + 64 * c];
+            t1[c] += p[(size_t)(j + 1) * d + 64 * c];
+        }
+    }
+    if (j < deg) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t0[c] += p[(size_t)j * d + 64 * c];
+    }
+    float x[CPL];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < RS_PER_LANE; ++c) {
-        const int o = lane + 64 * c;
-        x[c] = 0.f;
-        if (o < d) {
-            const float* __restrict__ p = Y + (size_t)p0 * d + o;
-            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-            int64_t j = 0;
-            for (; j + 4 <= deg; j += 4) {
-                t0 += p[(size_t)j * d];
-                t1 += p[(size_t)(j + 1) * d];
-                t2 += p[(size_t)(j + 2) * d];
-                t3 += p[(size_t)(j + 3) * d];
-            }
-            for (; j < deg; ++j) t0 += p[(size_t)j * d];
-            const float tt = ((t0 + t1) + (t2 + t3)) * inv;
-            x[c] = no_tail ? tt : fmaxf(tt + h[(size_t)v * d + o], 0.f);
-            s += x[c];
-        }
+    for (int c = 0; c < CPL; ++c) {
+        const float tt = (t0[c] + t1[c]) * inv;
+        x[c] = no_tail ? tt : fmaxf(tt + hv[c], 0.f);
+        s += x[c];
     }
     if (!no_tail) {
-        const float mean = wave_sum(s) / (float)d;
+        const float mean = wave_sum(s) * (1.0f / d);
         float var = 0.f;
 #pragma unroll
-        for (int c = 0; c < RS_PER_LANE; ++c)
-            if (lane + 64 * c < d) { const float tt = x[c] - mean; var += tt * tt; }
-        const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
+        for (int c = 0; c < CPL; ++c) { const float tt = x[c] - mean; var += tt * tt; }
+        const float rstd = 1.0f / sqrtf(wave_sum(var) * (1.0f / d) + eps);
 #pragma unroll
-        for (int c = 0; c < RS_PER_LANE; ++c) {
-            const int o = lane + 64 * c;
-            if (o < d) x[c] = (x[c] - mean) * rstd * g[o] + b[o];
-        }
+        for (int c = 0; c < CPL; ++c) x[c] = (x[c] - mean) * rstd * g[lane + 64 * c] + b[lane + 64 * c];
     }
 #pragma unroll
-    for (int c = 0; c < RS_PER_LANE; ++c) {
-        const int o = lane + 64 * c;
-        if (o < d) h_out[(size_t)v * d + o] = x[c];
-    }
+    for (int c = 0; c < CPL; ++c) h_out[(size_t)v * d + lane + 64 * c] = x[c];
 }
 
 int message_rs_supported(int d) { return d >= 256 && d <= RS_MAX_D && (d % RS_TN) == 0; }
@@ -180,13 +220,31 @@ int launch_edge_transform(const float* h, int64_t N, int d, const int64_t* src, 
     return GHF_OK;
 }
 
-int launch_segment_tail(const float* Y, const int64_t* off, const float* h, const float* g, const float* b, float eps,
-                        int64_t row0, int64_t rows, int d, float* h_out, int flags, hipStream_t stream) {
-    GHF_REQUIRE(d >= 1 && d <= RS_MAX_D, "segment_tail: d=%d outside [1,%d]", d, RS_MAX_D);
+int launch_segment_partial(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, hipStream_t stream) {
+    GHF_REQUIRE(d >= 1 && d <= RS_MAX_D, "segment_partial: d=%d outside [1,%d]", d, RS_MAX_D);
+    if (nchunks <= 0) return GHF_OK;
+    GHF_REQUIRE(nchunks < (1ll << 31), "segment_partial: too many chunks");
+    segment_partial_kernel<<<(unsigned)nchunks, 256, 0, stream>>>(Y, hub_chunks, d, P);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
+                        const float* h, const float* g, const float* b, float eps, int64_t row0, int64_t rows, int d,
+                        float* h_out, int flags, hipStream_t stream) {
+    GHF_REQUIRE(message_rs_supported(d), "segment_tail: d = %d is not a relation-stationary width", d);
     if (rows <= 0) return GHF_OK;
     GHF_REQUIRE(cdiv(rows, 4) < (1ll << 31), "segment_tail: too many rows per launch");
-    segment_tail_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, stream>>>(Y, off, h, g, b, eps, row0, row0 + rows, d, h_out,
-                                                                     flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
+    const unsigned grid = (unsigned)cdiv(rows, 4);
+    const int nt = flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM);
+    switch (d / 64) {
+#define GHF_RS_CASE(CPL)                                                                                                        \
+    case CPL:                                                                                                                   \
+        segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out, nt); \
+        break;
+        GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)
+#undef GHF_RS_CASE
+    }
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

@@ -38,7 +38,17 @@ class RsPlan:
     ypos: torch.Tensor       # [E] int64: the edge's position in destination order = its row of the per-edge results
     slice_tab: torch.Tensor  # [S, 3] int64 (relation, first edge, end edge): tiles of at most RS_TILE edges
     off: torch.Tensor        # [N+1] int64: a destination's rows of the per-edge results
+    hub_of: Optional[torch.Tensor] = None      # [N] int32: hub index or -1 (None: no destination has more than RS_HUB_ROWS rows)
+    hub_tab: Optional[torch.Tensor] = None     # [H, 2] int64: (first slot, slots) of a hub's chunk sums
+    hub_chunks: Optional[torch.Tensor] = None  # [C, 3] int64: (first row, end row, slot)
     _Y: Optional[torch.Tensor] = None
+    _P: Optional[torch.Tensor] = None
+
+    def hub_scratch(self, d: int) -> torch.Tensor:
+        n = self.hub_chunks.size(0) * d
+        if self._P is None or self._P.numel() < n:
+            self._P = torch.empty(n, dtype=torch.float32, device=self.off.device)
+        return self._P
 
     def scratch(self, E: int, d: int, device) -> torch.Tensor:
         if self._Y is None or self._Y.numel() < E * d:
@@ -47,6 +57,7 @@ class RsPlan:
 
 
 RS_TILE = 128
+RS_HUB_ROWS = 4096           # a destination with more rows than this is summed in chunks of this many by whole workgroups
 SRC_MASK = 0x0FFFFFFF
 
 
@@ -70,8 +81,22 @@ def build_rs(plan: "GraphPlan") -> RsPlan:
     for r, c in enumerate(counts):
         tab += [(r, a, min(a + RS_TILE, e + c)) for a in range(e, e + c, RS_TILE)]
         e += c
-    return RsPlan(src=src.index_select(0, perm).contiguous(), dst=dst.index_select(0, perm).contiguous(), ypos=perm.contiguous(),
-                  slice_tab=torch.tensor(tab, dtype=torch.int64).to(dev), off=off)
+    rs = RsPlan(src=src.index_select(0, perm).contiguous(), dst=dst.index_select(0, perm).contiguous(), ypos=perm.contiguous(),
+                slice_tab=torch.tensor(tab, dtype=torch.int64).to(dev), off=off)
+    hubs = torch.nonzero(plan.indeg > RS_HUB_ROWS).flatten()
+    if hubs.numel():
+        hub_nodes = hubs.cpu().tolist()
+        starts = off.index_select(0, hubs).cpu().tolist()
+        ends = off.index_select(0, hubs + 1).cpu().tolist()
+        chunks, htab = [], []
+        for a, b_ in zip(starts, ends):
+            htab.append((len(chunks), -(-(b_ - a) // RS_HUB_ROWS)))
+            chunks += [(p, min(p + RS_HUB_ROWS, b_), len(chunks) + i) for i, p in enumerate(range(a, b_, RS_HUB_ROWS))]
+        hub_of = torch.full((N,), -1, dtype=torch.int32)
+        hub_of[torch.tensor(hub_nodes)] = torch.arange(len(hub_nodes), dtype=torch.int32)
+        rs.hub_of, rs.hub_tab = hub_of.to(dev), torch.tensor(htab, dtype=torch.int64).to(dev)
+        rs.hub_chunks = torch.tensor(chunks, dtype=torch.int64).to(dev)
+    return rs
 
 
 @dataclass

@@ -712,10 +712,11 @@ def test_captured_hip_graph_replays_the_forward(name):
 
 @pytest.mark.parametrize("d,N,E,R,kind", [(256, 700, 9000, 9, "uniform"), (256, 300, 20000, 5, "powerlaw"), (384, 90, 60, 7, "uniform"),
                                           (256, 1500, 1200, 40, "powerlaw")])
-def test_wide_rows_layer_matches_oracle(d, N, E, R, kind):
+def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, monkeypatch):
     """csrc/message_rs.hip (d % 128 == 0, d >= 256): per-edge results in relation order + destination sums + tail against
     the oracle and against the generic kernel; tiles shorter than 128 edges, relations without edges, hubs, isolated rows,
     row ranges, NO_TAIL and RAW_SUM."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
     from graph_hypernetwork_forge_amd.plan import build_rs
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=11 + d + R, kind=kind)
     rel = np.where(rel == R - 1, 0, rel)                                # the last relation stays empty
@@ -723,8 +724,10 @@ def test_wide_rows_layer_matches_oracle(d, N, E, R, kind):
     th = torch.from_numpy
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
     assert plan.block_nodes == 1 and _native.rs_supported(d)
+    monkeypatch.setattr(plan_mod, "RS_HUB_ROWS", 700)                   # a hub's rows in chunks at this size
     rs = build_rs(plan)
     assert rs.slice_tab.size(0) >= E // 128 and int(rs.off[-1]) == E
+    assert (rs.hub_of is not None) == (kind == "powerlaw" and E > 5000), "the power-law cases must exercise the hub path"
     Y = torch.full((E, d), float("nan"), device=DEV)
     WmT, WsT = _native.transpose_batched(t(Wm)), _native.transpose_batched(t(Ws))
     _native.edge_transform_fwd(t(h), rs, WmT, WsT, t(b), Y)
