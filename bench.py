@@ -37,6 +37,9 @@ WORKLOADS = {
                desc="synthetic uniform KG 1M nodes / 10M edges / 64 rel, hidden 128, L=3 (BASELINE config 3)"),
     "c2": dict(N=100_000, E=1_000_000, R=32, d=64, L=2, T=64, seed=1002,
                desc="synthetic uniform KG 100k nodes / 1M edges / 32 rel, hidden 64, L=2 (BASELINE config 2)"),
+    # not a default: 64 GB of per-edge results on one GPU, a 64M-entry edge_texts list on the host
+    "c5": dict(N=4_000_000, E=64_000_000, R=256, d=256, L=4, T=64, seed=1005, kind="powerlaw",
+               desc="synthetic power-law KG 4M nodes / 64M edges / 256 rel, hidden 256, L=4 (BASELINE config 5)"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MATRIX_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
@@ -125,7 +128,7 @@ def main():
     N, E, R, d, L, T = (cfg[k] for k in ("N", "E", "R", "d", "L", "T"))
 
     t0 = time.time()
-    ei_np, rel_np = synth.make_graph_arrays(N, E, R, cfg["seed"])
+    ei_np, rel_np = synth.make_graph_arrays(N, E, R, cfg["seed"], cfg.get("kind", "uniform"))
     names = synth.relation_names(R)
     edge_texts = [names[i] for i in rel_np.tolist()]
     edge_index = torch.from_numpy(ei_np).to(dev)
@@ -182,8 +185,19 @@ def main():
         hs = _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
         ln = model.layer_norms[0]
         slots = [(0, N)] if world == 1 else runner._spec.owned()     # this rank's destination rows
+        wide = plan.block_nodes == 1 and _native.rs_supported(d)     # relation-stationary layer (csrc/message_rs.hip)
+        if wide:
+            from graph_hypernetwork_forge_amd.plan import build_rs
+            plan.rs = plan.rs or build_rs(plan)
+            WmT, WsT = _native.transpose_batched(W), _native.transpose_batched(W_self)
+            Y = plan.rs.scratch(plan.E, d, dev)
 
         def msg():
+            if wide:
+                _native.edge_transform_fwd(h, plan.rs, WmT, WsT, bias, Y)
+                for lo, hi in slots:
+                    _native.segment_tail_fwd(Y, plan.rs, h, ln.weight, ln.bias, ln.eps, h_out, row0=lo, rows=hi - lo)
+                return
             for lo, hi in slots:
                 _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, ln.weight, ln.bias, ln.eps, h_out,
                                           row0=lo, rows=hi - lo, h_split=hs)
@@ -214,6 +228,8 @@ def main():
             traffic_src = "profiles/r01_message_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2)"
         kern = {_native.WLAYOUT_SPLIT2H: "message_hx_kernel<128>", _native.WLAYOUT_SPLIT3: "message_sx_kernel<128>"}.get(
             plan.wlayout, "message_pp_kernel<%d>" % d if plan.block_nodes > 1 else "message_generic_kernel")
+        if wide:
+            kern = "edge_transform_kernel + segment_tail_kernel<%d> (one layer)" % (d // 64)
         # matrix work the kernel issues per algorithmic flop: 3 fp16 products (hx), 6 bf16 products (sx), 1 fp32 (pp)
         prod, mpeak = {_native.WLAYOUT_SPLIT2H: (3, F16_MATRIX_PEAK_TF), _native.WLAYOUT_SPLIT3: (6, F16_MATRIX_PEAK_TF)}.get(
             plan.wlayout, (1, FP32_MATRIX_PEAK_TF))
