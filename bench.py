@@ -189,12 +189,11 @@ def main():
         if wide:
             from graph_hypernetwork_forge_amd.plan import build_rs
             plan.rs = plan.rs or build_rs(plan)
-            WmT, WsT = _native.transpose_batched(W), _native.transpose_batched(W_self)
             Y = plan.rs.scratch(plan.E, d, dev)
 
         def msg():
             if wide:
-                _native.edge_transform_fwd(h, plan.rs, WmT, WsT, bias, Y)
+                _native.edge_transform_fwd(h, plan.rs, W, W_self, bias, Y)        # incl. cutting h and the weights into pieces
                 for lo, hi in slots:
                     _native.segment_tail_fwd(Y, plan.rs, h, ln.weight, ln.bias, ln.eps, h_out, row0=lo, rows=hi - lo)
                 return
@@ -233,6 +232,8 @@ def main():
         # matrix work the kernel issues per algorithmic flop: 3 fp16 products (hx), 6 bf16 products (sx), 1 fp32 (pp)
         prod, mpeak = {_native.WLAYOUT_SPLIT2H: (3, F16_MATRIX_PEAK_TF), _native.WLAYOUT_SPLIT3: (6, F16_MATRIX_PEAK_TF)}.get(
             plan.wlayout, (1, FP32_MATRIX_PEAK_TF))
+        if wide and not _native.rs_exact():
+            prod, mpeak = 3, F16_MATRIX_PEAK_TF
         l2_bytes = None
         if traffic is not None and "TCC_REQ_sum" in pmc:
             l2_bytes = pmc["TCC_REQ_sum"] * 128.0

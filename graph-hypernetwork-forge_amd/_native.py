@@ -61,6 +61,9 @@ SIGNATURES = {
     "ghf_group_outer": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "ghf_message_rs_supported": (_i32, [_i32]),
     "ghf_edge_transform_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ghf_weights_rs_bytes": (_sz, [_i32, _i32]),
+    "ghf_weights_pack_rs": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "ghf_edge_transform_h_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "ghf_segment_partial_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
@@ -314,14 +317,32 @@ def rs_supported(d: int) -> bool:
     return bool(load().ghf_message_rs_supported(d)) and os.environ.get("GHF_KERNEL") != "generic"
 
 
-def edge_transform_fwd(h: torch.Tensor, rs, WmT: torch.Tensor, WsT: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
-    """Pass 1: per-edge results into Y [E, d] at the edges' destination-order positions (rs: plan.RsPlan)."""
+def rs_exact() -> bool:
+    """GHF_KERNEL=rs32: the wide-row layer's pass 1 on fp32 MFMAs (exact fma chain) instead of two fp16 pieces."""
+    return os.environ.get("GHF_KERNEL") == "rs32"
+
+
+def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+    """Pass 1: per-edge results into Y [E, d] at the edges' destination-order positions (rs: plan.RsPlan; W_msg / W_self
+    natural [R, d, d]).  Cuts h and the weights into their two fp16 pieces first (or transposes the weights, rs32)."""
+    lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
-    _check(load().ghf_edge_transform_fwd(_ptr(h), N, d, _ptr(rs.src), _ptr(rs.dst), _ptr(rs.ypos), _ptr(rs.slice_tab),
-                                         rs.slice_tab.size(0), _ptr(_req(WmT, torch.float32, "WmT")),
-                                         _ptr(_req(WsT, torch.float32, "WsT")), _ptr(_req(bias, torch.float32, "bias")),
-                                         _ptr(Y), _stream()), "ghf_edge_transform_fwd")
+    R = W_msg.size(0)
+    Wm, Ws = _req(W_msg, torch.float32, "W_msg"), _req(W_self, torch.float32, "W_self")
+    if rs_exact():
+        WmT, WsT = transpose_batched(Wm), transpose_batched(Ws)      # (named: they must outlive the launch's pointer taking)
+        _check(lib.ghf_edge_transform_fwd(_ptr(h), N, d, _ptr(rs.src), _ptr(rs.dst), _ptr(rs.ypos), _ptr(rs.slice_tab),
+                                          rs.slice_tab.size(0), _ptr(WmT), _ptr(WsT),
+                                          _ptr(_req(bias, torch.float32, "bias")), _ptr(Y), _stream()), "ghf_edge_transform_fwd")
+    else:
+        hs = split_rows(h, WLAYOUT_SPLIT2H)
+        w2h = torch.empty(lib.ghf_weights_rs_bytes(R, d), dtype=torch.uint8, device=h.device)
+        shift = torch.empty(R, dtype=torch.int32, device=h.device)
+        _check(lib.ghf_weights_pack_rs(_ptr(Wm), _ptr(Ws), R, d, _ptr(w2h), _ptr(shift), _stream()), "ghf_weights_pack_rs")
+        _check(lib.ghf_edge_transform_h_fwd(_ptr(hs), N, d, _ptr(rs.src), _ptr(rs.dst), _ptr(rs.ypos), _ptr(rs.slice_tab),
+                                            rs.slice_tab.size(0), _ptr(w2h), R, _ptr(_req(bias, torch.float32, "bias")), _ptr(Y),
+                                            _stream()), "ghf_edge_transform_h_fwd")
     if rs.hub_of is not None:                       # hubs: their rows in chunks (fixed order); pass 2 adds the chunks' sums
         _check(load().ghf_segment_partial_fwd(_ptr(Y), _ptr(rs.hub_chunks), rs.hub_chunks.size(0), d, _ptr(rs.hub_scratch(d)),
                                               _stream()), "ghf_segment_partial_fwd")

@@ -202,6 +202,20 @@ int ghf_edge_transform_fwd(const float* h, int64_t N, int d, const int64_t* src,
     return launch_edge_transform(h, N, d, src, dst, ypos, slice_tab, nslices, WmT, WsT, bias, Y, (hipStream_t)stream);
 }
 
+size_t ghf_weights_rs_bytes(int R, int d) { return weights_rs_bytes(R, d); }
+
+int ghf_weights_pack_rs(const float* W_msg, const float* W_self, int R, int d, void* w2h, int* shift_ws, void* stream) {
+    GHF_REQUIRE(W_msg && W_self && w2h && shift_ws, "weights_pack_rs: null pointer argument");
+    return launch_weights_pack_rs(W_msg, W_self, R, d, w2h, shift_ws, (hipStream_t)stream);
+}
+
+int ghf_edge_transform_h_fwd(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
+                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
+                             void* stream) {
+    GHF_REQUIRE(h_split && src && dst && ypos && slice_tab && w2h && bias && Y, "edge_transform_h_fwd: null pointer argument");
+    return launch_edge_transform_h(h_split, N, d, src, dst, ypos, slice_tab, nslices, w2h, R, bias, Y, (hipStream_t)stream);
+}
+
 int ghf_segment_partial_fwd(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, void* stream) {
     GHF_REQUIRE((Y && hub_chunks && P) || nchunks == 0, "segment_partial_fwd: null pointer argument");
     return launch_segment_partial(Y, hub_chunks, nchunks, d, P, (hipStream_t)stream);

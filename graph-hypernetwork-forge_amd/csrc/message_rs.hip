@@ -18,6 +18,8 @@
 // same k-permutation on both operands).
 #include "common.h"
 
+#include <type_traits>
+
 namespace ghf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -111,6 +113,196 @@ __global__ __launch_bounds__(256) void edge_transform_kernel(
                 for (int ct = 0; ct < 8; ++ct) y[16 * ct] = acc[rt][ct][s] + bv[ct];
             }
         }
+}
+
+// ---- pass 1 with the contraction of message_hx.hip: two fp16 pieces per operand, three 16x16x32 products -----------
+// (its header: x 2^s = hi + lo, hi*hi + hi*lo + lo*hi in fp32, the exact scales taken out again).  Operands:
+//   h_split        ghf_split_rows(h, SPLIT2H): N rows [hi d | lo d] fp16, then N float 2^-s(row)
+//   w2h            ghf_weights_pack_rs: per relation [half: msg, self][piece: hi, lo][n][k] fp16 (TRANSPOSED: k contiguous),
+//                  all relations, then R float 2^-s(relation)
+// K runs over the source half and then the destination half of a row pair; the two halves have different row scales:
+// between them the accumulators are multiplied by 2^-s(src) / 2^-s(dst) — a power of two, exact — so that one set
+// serves both (64 registers less: two waves per SIMD instead of one) and 2^-s(dst) 2^-s(relation) is taken out at the end.  Tiles per step: 32 k of 128 rows and 128 columns, both pieces (4 x 8 KB), double
+// buffered.  fp32 MFMA: 64 MFMAs x 32 cycles per 16 k; here 48 x 16 cycles per 32 k — 5.3 x less matrix time.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int RS_KH = 32;
+
+__global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
+    const char* __restrict__ h_split, int64_t N, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+    const int64_t* __restrict__ ypos, const int64_t* __restrict__ slice_tab, const char* __restrict__ w2h, int R,
+    const float* __restrict__ bias, float* __restrict__ Y) {
+    __shared__ __attribute__((aligned(16))) _Float16 At[2][2][RS_TM][RS_KH];      // [buffer][piece][row][k]
+    __shared__ __attribute__((aligned(16))) _Float16 Bt[2][2][RS_TN][RS_KH];
+    __shared__ float rsc[2][RS_TM];                                                // 2^-s of a tile row's source / destination row
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const unsigned ncol = (unsigned)d / RS_TN, tile = blockIdx.x / ncol;
+    const int64_t r = slice_tab[3 * (size_t)tile], e0 = slice_tab[3 * (size_t)tile + 1], e1 = slice_tab[3 * (size_t)tile + 2];
+    const int n0 = (int)(blockIdx.x % ncol) * RS_TN;
+    const size_t hrow = (size_t)4 * d;                     // bytes per split row
+    const float* __restrict__ hscale = (const float*)(h_split + (size_t)N * hrow);
+    // staging map: thread t moves the 16-byte granules (row t/2, k 8 (2 (t%2) + i) .. +7), i = 0, 1, of both pieces
+    const int srow = t >> 1, sg = 2 * (t & 1);
+    int64_t e = e0 + srow;
+    if (e >= e1) e = e1 - 1;                               // rows past the tile's end repeat its last edge (never stored)
+    const int64_t su = src[e], sv = dst[e];
+    if ((t & 1) == 0) {
+        rsc[0][srow] = hscale[su];
+        rsc[1][srow] = hscale[sv];
+    }
+    const char* __restrict__ wr = w2h + (size_t)r * 8 * d * d;          // [half][piece][n][k] fp16 = 8 d^2 bytes per relation
+    const float wscale = ((const float*)(w2h + (size_t)R * 8 * d * d))[r];
+    // Four register sets: the rows of a step are requested three steps before they are written to LDS — this kernel's 293
+    // registers leave one wave per SIMD, so a gather's latency (an HBM miss, ~2 us) has to be covered by this wave's own
+    // MFMAs (768 cycles per step).
+    struct Stage { i32x4 a[2][2], b[2][2]; };              // [piece][i]
+    Stage st[4];
+    auto fetch = [&](int k0, Stage& S) {                   // k0: first contraction index of the step, in [0, 2d)
+        const int half = k0 >= d;
+        const int kk = half ? k0 - d : k0;
+        const char* arow = h_split + (size_t)(half ? sv : su) * hrow;
+        const char* brow = wr + ((size_t)half * 2 * d + (n0 + srow)) * (size_t)d * 2;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                S.a[pl][i] = *(const i32x4*)(arow + (size_t)pl * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
+                S.b[pl][i] = *(const i32x4*)(brow + (size_t)pl * d * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
+            }
+    };
+    auto commit = [&](int buf, const Stage& S) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *(i32x4*)&At[buf][pl][srow][8 * (sg + i)] = S.a[pl][i];
+                *(i32x4*)&Bt[buf][pl][srow][8 * (sg + i)] = S.b[pl][i];
+            }
+    };
+
+    f32x4 acc[2][8];                                       // [row tile][column tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int half_steps = d / RS_KH, total = 2 * half_steps;              // (d % 128 == 0: half_steps % 4 == 0)
+    fetch(0, st[0]);
+    fetch(1 * RS_KH, st[1]);
+    fetch(2 * RS_KH, st[2]);
+    commit(0, st[0]);
+    __syncthreads();
+    auto run_step = [&](auto hf_tag, auto i_tag, int step) {
+        constexpr int hf = decltype(hf_tag)::value, i4 = decltype(i_tag)::value;
+        {
+            const int buf = step & 1;
+            const int pre = step + 3 < total ? step + 3 : total - 1;       // (past the end: the last step again, no branch around loads)
+            fetch(pre * RS_KH, st[(i4 + 3) & 3]);
+            i32x4 a[2][2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[rt][pl] = *(const i32x4*)&At[buf][pl][32 * w + 16 * rt + c16][8 * q];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {               // the column tiles in two groups of four: 32 fragment registers live, not 64
+                i32x4 b[4][2];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) b[c4][pl] = *(const i32x4*)&Bt[buf][pl][16 * (4 * ch + c4) + c16][8 * q];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const int ct = 4 * ch + c4;
+                        auto fma = [&](int pa, int pb) {
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt][pa]),
+                                                                                 __builtin_bit_cast(f16x8, b[c4][pb]), acc[rt][ct], 0, 0, 0);
+                        };
+                        fma(1, 0); fma(0, 1);              // lo*hi, hi*lo
+                        fma(0, 0);                         // hi*hi
+                    }
+            }
+            commit(buf ^ 1, st[(i4 + 1) & 3]);
+            __syncthreads();
+        }
+    };
+    auto run_half = [&](auto hf_tag) {
+        constexpr int hf = decltype(hf_tag)::value;
+        for (int s = 0; s < half_steps; s += 4) {
+            const int step = hf * half_steps + s;
+            run_step(hf_tag, std::integral_constant<int, 0>{}, step);
+            run_step(hf_tag, std::integral_constant<int, 1>{}, step + 1);
+            run_step(hf_tag, std::integral_constant<int, 2>{}, step + 2);
+            run_step(hf_tag, std::integral_constant<int, 3>{}, step + 3);
+        }
+    };
+    run_half(std::integral_constant<int, 0>{});
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)                         // from the source rows' scale to the destination rows' (exact)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = 32 * w + 16 * rt + 4 * q + s;
+            const float ratio = rsc[0][row] / rsc[1][row];
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) acc[rt][ct][s] *= ratio;
+        }
+    run_half(std::integral_constant<int, 1>{});
+    // D: lane holds rows 4q + s, column c16 of a tile
+    float bv[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = bias[(size_t)r * d + n0 + 16 * ct + c16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = 32 * w + 16 * rt + 4 * q + s;
+            const int64_t ee = e0 + row;
+            if (ee < e1) {
+                const float fv = rsc[1][row] * wscale;
+                float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + c16;
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) y[16 * ct] = fmaf(acc[rt][ct][s], fv, bv[ct]);
+            }
+        }
+}
+
+// ghf_weights_pack_rs: natural W_msg, W_self [R][d][d] -> w2h (see above).  One workgroup per relation finds the
+// largest magnitude of both matrices; a second kernel scales, cuts and transposes.
+__global__ __launch_bounds__(256) void rs_wmax_kernel(const float* __restrict__ Wm, const float* __restrict__ Ws, int d,
+                                                      float* __restrict__ inv_scale, int* __restrict__ shift) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const size_t n = (size_t)d * d;
+    float mx = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, fmaxf(fabsf(Wm[r * n + i]), fabsf(Ws[r * n + i])));
+    mx = wave_absmax(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int sh = split2h_shift(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        shift[r] = sh;
+        inv_scale[r] = pow2f(-sh);
+    }
+}
+__global__ __launch_bounds__(256) void rs_wpack_kernel(const float* __restrict__ Wm, const float* __restrict__ Ws, int d,
+                                                       const int* __restrict__ shift, _Float16* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int r = blockIdx.z >> 1, half = blockIdx.z & 1;
+    const float* __restrict__ W = (half ? Ws : Wm) + (size_t)r * d * d;             // natural [k][n]
+    const float up = pow2f(shift[r]);
+    const int k0 = blockIdx.y * 32, nn0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 1024; i += 256) tile[i >> 5][i & 31] = W[(size_t)(k0 + (i >> 5)) * d + nn0 + (i & 31)];
+    __syncthreads();
+    _Float16* __restrict__ base = out + ((size_t)r * 4 + (size_t)half * 2) * d * d;    // [piece][n][k]
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int n = nn0 + (i >> 5), k = k0 + (i & 31);
+        _Float16 hi, lo;
+        split2h(tile[i & 31][i >> 5] * up, hi, lo);
+        base[(size_t)n * d + k] = hi;
+        base[(size_t)d * d + (size_t)n * d + k] = lo;
+    }
 }
 
 constexpr int RS_MAX_D = 1024, RS_PER_LANE = RS_MAX_D / 64;
@@ -216,6 +408,32 @@ int launch_edge_transform(const float* h, int64_t N, int d, const int64_t* src, 
     GHF_REQUIRE(N > 0 && nslices > 0 && nslices < (1ll << 31), "edge_transform: bad sizes");
     edge_transform_kernel<<<dim3((unsigned)nslices, (unsigned)(d / RS_TN)), 256, 0, stream>>>(h, d, src, dst, ypos, slice_tab,
                                                                                             WmT, WsT, bias, Y);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+size_t weights_rs_bytes(int R, int d) { return (size_t)R * 8 * d * d + (size_t)R * 4; }
+
+int launch_weights_pack_rs(const float* Wm, const float* Ws, int R, int d, void* out, int* shift_ws, hipStream_t stream) {
+    GHF_REQUIRE(message_rs_supported(d) && R > 0, "weights_pack_rs: d = %d is not a relation-stationary width", d);
+    float* inv = (float*)((char*)out + (size_t)R * 8 * d * d);
+    rs_wmax_kernel<<<R, 256, 0, stream>>>(Wm, Ws, d, inv, shift_ws);
+    GHF_LAUNCH_CHECK();
+    rs_wpack_kernel<<<dim3(d / 32, d / 32, 2 * R), 256, 0, stream>>>(Wm, Ws, d, shift_ws, (_Float16*)out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
+                            const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
+                            hipStream_t stream) {
+    GHF_REQUIRE(message_rs_supported(d), "edge_transform: d = %d has no relation-stationary kernel (d %% 128 == 0, 256 <= d <= %d)", d, RS_MAX_D);
+    GHF_REQUIRE(N > 0 && nslices > 0 && nslices < (1ll << 31), "edge_transform: bad sizes");
+    // (one-dimensional grid, the column tile the fast index: the workgroups that share a tile's rows run side by side
+    // and share them in L2)
+    GHF_REQUIRE(nslices * (d / RS_TN) < (1ll << 31), "edge_transform: too many tiles per launch");
+    edge_transform_h_kernel<<<(unsigned)(nslices * (d / RS_TN)), 256, 0, stream>>>(
+        (const char*)h_split, N, d, src, dst, ypos, slice_tab, (const char*)w2h, R, bias, Y);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

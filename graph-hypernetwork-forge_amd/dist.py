@@ -117,8 +117,7 @@ class NativeOps:
             if plan.rs is None:
                 plan.rs = build_rs(plan)
             W_msg, W_self, bias = weights
-            _native.edge_transform_fwd(h, plan.rs, _native.transpose_batched(W_msg), _native.transpose_batched(W_self), bias,
-                                       plan.rs.scratch(plan.E, h.size(1), h.device))
+            _native.edge_transform_fwd(h, plan.rs, W_msg, W_self, bias, plan.rs.scratch(plan.E, h.size(1), h.device))
 
     def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int, h_split_out=None) -> None:
         norm = model.layer_norms[l]

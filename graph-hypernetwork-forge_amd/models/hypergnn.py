@@ -308,7 +308,7 @@ class HyperGNN(nn.Module):
         for gen, norm in zip(self.weight_generators, self.layer_norms):
             W_msg, W_self, bias = gen.generate(text_embs, _native.WLAYOUT_NATURAL)
             if plan.E > 0:
-                _native.edge_transform_fwd(h, rs, _native.transpose_batched(W_msg), _native.transpose_batched(W_self), bias, Y)
+                _native.edge_transform_fwd(h, rs, W_msg, W_self, bias, Y)
             _native.segment_tail_fwd(Y, rs, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo)
             if exchange is not None:
                 exchange(h_next)

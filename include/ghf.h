@@ -174,12 +174,20 @@ int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
  *       (src / dst / ypos [E] int64: the edge's ends and its position in destination order); slice_tab [nslices][3] int64 =
  *       (relation, first edge, end edge) cuts every relation's range into tiles of at most 128 edges; WmT / WsT [R][d][d]
  *       are the weights TRANSPOSED ([r][out][in], ghf_transpose_batched of the natural layout); Y [E][d] fp32 scratch.
+ *   ghf_edge_transform_h_fwd: the same per-edge results with the two-fp16-piece contraction of the d = 128 kernel (three
+ *       16x16x32 products, 22 significand bits, 5x less matrix time): h_split = ghf_split_rows(h, GHF_WLAYOUT_SPLIT2H), w2h =
+ *       ghf_weights_pack_rs(W_msg, W_self natural [R][d][d]) (ghf_weights_rs_bytes(R, d) bytes; shift_ws: R ints of scratch).
  *   ghf_segment_partial_fwd (hubs only): P[slot] = sum(Y[first .. end)) for every (first, end, slot) of hub_chunks
  *       [nchunks][3] int64 — a destination with more rows than one wave should walk is summed in chunks first.
  *   ghf_segment_tail_fwd: rows [row0, row0+rows): out_v = sum(Y[off[v] .. off[v+1])) / max(indeg, 1), then the tail of
  *       ghf_tail_fwd (flags: GHF_FLAG_NO_TAIL / GHF_FLAG_RAW_SUM as for the message layer); off [N+1] int64.  Hubs:
  *       hub_of [N] int32 (hub index or -1; NULL = no hubs), hub_tab [H][2] int64 (first slot, slots) select rows of P
  *       to add instead of rows of Y; the mean still divides by off[v+1] - off[v]. */
+size_t ghf_weights_rs_bytes(int R, int d);
+int ghf_weights_pack_rs(const float* W_msg, const float* W_self, int R, int d, void* w2h, int* shift_ws, void* stream);
+int ghf_edge_transform_h_fwd(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
+                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
+                             void* stream);
 int ghf_segment_partial_fwd(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, void* stream);
 int ghf_message_rs_supported(int d);
 int ghf_edge_transform_fwd(const float* h, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,

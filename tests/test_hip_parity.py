@@ -712,12 +712,15 @@ def test_captured_hip_graph_replays_the_forward(name):
 
 @pytest.mark.parametrize("d,N,E,R,kind", [(256, 700, 9000, 9, "uniform"), (256, 300, 20000, 5, "powerlaw"), (384, 90, 60, 7, "uniform"),
                                           (256, 1500, 1200, 40, "powerlaw")])
-def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, monkeypatch):
+@pytest.mark.parametrize("exact", [False, True])
+def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, exact, monkeypatch):
     """csrc/message_rs.hip (d % 128 == 0, d >= 256): per-edge results in relation order + destination sums + tail against
     the oracle and against the generic kernel; tiles shorter than 128 edges, relations without edges, hubs, isolated rows,
     row ranges, NO_TAIL and RAW_SUM."""
     from graph_hypernetwork_forge_amd import plan as plan_mod
     from graph_hypernetwork_forge_amd.plan import build_rs
+    if exact:
+        monkeypatch.setenv("GHF_KERNEL", "rs32")                         # pass 1 on fp32 MFMAs instead of two fp16 pieces
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=11 + d + R, kind=kind)
     rel = np.where(rel == R - 1, 0, rel)                                # the last relation stays empty
     t = lambda a: torch.from_numpy(a).to(DEV)                           # noqa: E731
@@ -729,8 +732,7 @@ def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, monkeypatch):
     assert rs.slice_tab.size(0) >= E // 128 and int(rs.off[-1]) == E
     assert (rs.hub_of is not None) == (kind == "powerlaw" and E > 5000), "the power-law cases must exercise the hub path"
     Y = torch.full((E, d), float("nan"), device=DEV)
-    WmT, WsT = _native.transpose_batched(t(Wm)), _native.transpose_batched(t(Ws))
-    _native.edge_transform_fwd(t(h), rs, WmT, WsT, t(b), Y)
+    _native.edge_transform_fwd(t(h), rs, t(Wm), t(Ws), t(b), Y)
     assert bool(torch.isfinite(Y).all()), "every edge's row of the per-edge results is written"
     agg = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
     ref = O.layer_tail(agg, th(h), th(gamma), th(beta))
@@ -738,7 +740,7 @@ def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, monkeypatch):
     _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, out)
     assert_close(out.cpu().numpy(), ref.numpy(), "wide-row layer")
     again = torch.empty_like(out)
-    _native.edge_transform_fwd(t(h), rs, WmT, WsT, t(b), Y)
+    _native.edge_transform_fwd(t(h), rs, t(Wm), t(Ws), t(b), Y)
     _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, again)
     assert torch.equal(out, again)
     raw = torch.empty_like(out)

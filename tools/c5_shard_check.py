@@ -25,15 +25,14 @@ t0 = time.time(); rs = build_rs(plan); torch.cuda.synchronize(); t_rs = time.tim
 h = torch.randn(N, d, device=dev); out = torch.empty_like(h)
 Wm = torch.randn(R, d, d, device=dev) * 0.05; Ws = torch.randn(R, d, d, device=dev) * 0.05
 b = torch.randn(R, d, device=dev); g = torch.ones(d, device=dev); bt = torch.zeros(d, device=dev)
-WmT, WsT = _native.transpose_batched(Wm), _native.transpose_batched(Ws)
 Y = rs.scratch(E, d, dev)
 def layer():
-    _native.edge_transform_fwd(h, rs, WmT, WsT, b, Y)
+    _native.edge_transform_fwd(h, rs, Wm, Ws, b, Y)
     _native.segment_tail_fwd(Y, rs, h, g, bt, 1e-5, out)
 for _ in range(2): layer()
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-ev[0].record(); _native.edge_transform_fwd(h, rs, WmT, WsT, b, Y); ev[1].record(); _native.segment_tail_fwd(Y, rs, h, g, bt, 1e-5, out); ev[2].record()
+ev[0].record(); _native.edge_transform_fwd(h, rs, Wm, Ws, b, Y); ev[1].record(); _native.segment_tail_fwd(Y, rs, h, g, bt, 1e-5, out); ev[2].record()
 torch.cuda.synchronize()
 p1, p2 = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 flops = 4.0 * E * d * d
