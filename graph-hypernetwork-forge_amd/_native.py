@@ -317,6 +317,19 @@ def rs_supported(d: int) -> bool:
     return bool(load().ghf_message_rs_supported(d)) and os.environ.get("GHF_KERNEL") != "generic"
 
 
+RS_MIN_RELATIONS = 128
+
+
+def prefer_rs(d: int, R: int) -> bool:
+    """Whether an inference plan for hidden size d and R relations should be a CSR plan for the relation-stationary layer:
+    always where no destination-block kernel exists (d >= 256); at d = 128 from about 128 relations on — the block
+    kernel re-streams a relation's weights per (block, relation) chunk, so its time grows with R (C3-sized graph: 4.1 ms per
+    layer at R = 64, 11.3 ms at 256) while the relation-stationary layer's does not (6.0 ms)."""
+    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("hx", "sx", "pp", "lockstep"):
+        return False
+    return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
+
+
 def rs_exact() -> bool:
     """GHF_KERNEL=rs32: the wide-row layer's pass 1 on fp32 MFMAs (exact fma chain) instead of two fp16 pieces."""
     return os.environ.get("GHF_KERNEL") == "rs32"

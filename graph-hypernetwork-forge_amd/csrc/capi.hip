@@ -35,8 +35,15 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
     // GHF_KERNEL selects the contraction for A/B runs: "hx" (default) = two fp16 pieces, three products
     // (message_hx.hip), "sx" = three bf16 pieces, six products (message_sx.hip), "pp" / "lockstep" =
     // v_mfma_f32_16x16x4_f32 (message_pp.hip / message_mfma.hip)
+    // "rs" / "rs32" / "generic": a CSR plan also where a destination-block kernel exists (A/B of the relation-stationary
+    // layer at d = 128)
     const char* kv = getenv("GHF_KERNEL");
-    if ((!kv || !strcmp(kv, "hx")) && message_hx_config(d, &bn, &cr, &sc)) {
+    if (kv && (!strcmp(kv, "rs") || !strcmp(kv, "rs32") || !strcmp(kv, "generic"))) {
+        *block_nodes = 1;
+        *wlayout = GHF_WLAYOUT_NATURAL;
+        *chunk_rows = 0;
+        *split_chunks = 0;
+    } else if ((!kv || !strcmp(kv, "hx")) && message_hx_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_SPLIT2H;
         *chunk_rows = cr;

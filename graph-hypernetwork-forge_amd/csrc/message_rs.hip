@@ -399,12 +399,13 @@ __global__ __launch_bounds__(256) void segment_tail_kernel(
     for (int c = 0; c < CPL; ++c) h_out[(size_t)v * d + lane + 64 * c] = x[c];
 }
 
-int message_rs_supported(int d) { return d >= 256 && d <= RS_MAX_D && (d % RS_TN) == 0; }
+// (d = 128 runs too — GHF_KERNEL=rs selects it there for A/B — but the destination-block kernel is the default at 128)
+int message_rs_supported(int d) { return d >= 128 && d <= RS_MAX_D && (d % RS_TN) == 0; }
 
 int launch_edge_transform(const float* h, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
                           const int64_t* slice_tab, int64_t nslices, const float* WmT, const float* WsT, const float* bias,
                           float* Y, hipStream_t stream) {
-    GHF_REQUIRE(message_rs_supported(d), "edge_transform: d = %d has no relation-stationary kernel (d %% 128 == 0, 256 <= d <= %d)", d, RS_MAX_D);
+    GHF_REQUIRE(message_rs_supported(d), "edge_transform: d = %d has no relation-stationary kernel (d %% 128 == 0, 128 <= d <= %d)", d, RS_MAX_D);
     GHF_REQUIRE(N > 0 && nslices > 0 && nslices < (1ll << 31), "edge_transform: bad sizes");
     edge_transform_kernel<<<dim3((unsigned)nslices, (unsigned)(d / RS_TN)), 256, 0, stream>>>(h, d, src, dst, ypos, slice_tab,
                                                                                             WmT, WsT, bias, Y);
@@ -427,7 +428,7 @@ int launch_weights_pack_rs(const float* Wm, const float* Ws, int R, int d, void*
 int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
                             hipStream_t stream) {
-    GHF_REQUIRE(message_rs_supported(d), "edge_transform: d = %d has no relation-stationary kernel (d %% 128 == 0, 256 <= d <= %d)", d, RS_MAX_D);
+    GHF_REQUIRE(message_rs_supported(d), "edge_transform: d = %d has no relation-stationary kernel (d %% 128 == 0, 128 <= d <= %d)", d, RS_MAX_D);
     GHF_REQUIRE(N > 0 && nslices > 0 && nslices < (1ll << 31), "edge_transform: bad sizes");
     // (one-dimensional grid, the column tile the fast index: the workgroups that share a tile's rows run side by side
     // and share them in L2)
@@ -460,7 +461,7 @@ int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_o
     case CPL:                                                                                                                   \
         segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out, nt); \
         break;
-        GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)
+        GHF_RS_CASE(2) GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)
 #undef GHF_RS_CASE
     }
     GHF_LAUNCH_CHECK();

@@ -78,7 +78,8 @@ class NativeOps:
         return _native.message_config(d)
 
     def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner) -> GraphPlan:
-        return build_plan(edge_index, rel_ids, unique, N, d, device, owner=owner)
+        return build_plan(edge_index, rel_ids, unique, N, d, device, owner=owner,
+                          force_generic=_native.prefer_rs(d, len(unique)))
 
     def text_embs(self, model, unique: Sequence[str], device) -> torch.Tensor:
         return model.text_encoder(unique, device)

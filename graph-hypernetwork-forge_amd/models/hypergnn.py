@@ -134,13 +134,16 @@ class HyperGNN(nn.Module):
 
     # -- plan ------------------------------------------------------------------------------
     def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], num_nodes: int,
-                 device: torch.device) -> GraphPlan:
-        """Cached graph plan for these inputs (cold: O(E) host work + one device sort)."""
-        key = PlanCache.key(edge_index, edge_texts, num_nodes, self.hidden_dim, device)
+                 device: torch.device, training: bool = False) -> GraphPlan:
+        """Cached graph plan for these inputs (cold: O(E) host work + one device sort).  Inference plans of graphs with
+        many relations are CSR plans for the relation-stationary layer (_native.prefer_rs); plans that will record
+        gradients keep the destination-block geometry the backward kernels run on."""
+        key = PlanCache.key(edge_index, edge_texts, num_nodes, self.hidden_dim, device) + (bool(training),)
         plan = self._plans.get(key)
         if plan is None:
             unique, ids = relation_ids(edge_texts)
-            plan = build_plan(edge_index, torch.from_numpy(ids), unique, num_nodes, self.hidden_dim, device)
+            wide = not training and _native.prefer_rs(self.hidden_dim, len(unique))
+            plan = build_plan(edge_index, torch.from_numpy(ids), unique, num_nodes, self.hidden_dim, device, force_generic=wide)
             self._plans.put(key, plan, edge_index, edge_texts)
         return plan
 
@@ -175,10 +178,11 @@ class HyperGNN(nn.Module):
         texts = list(relation_texts)
         key = ("ids", edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
                edge_rel_ids.data_ptr(), edge_rel_ids._version, str(edge_rel_ids.device), tuple(texts), N, self.hidden_dim,
-               str(device))
+               str(device), bool(grad))
         plan = self._plans.get(key)
         if plan is None:
-            plan = build_plan(edge_index, edge_rel_ids, texts, N, self.hidden_dim, device)   # ids out of range: IndexError
+            wide = not grad and _native.prefer_rs(self.hidden_dim, len(texts))
+            plan = build_plan(edge_index, edge_rel_ids, texts, N, self.hidden_dim, device, force_generic=wide)   # ids out of range: IndexError
             self._plans.put(key, plan, edge_index, (edge_rel_ids, texts))
         if grad:
             return self._forward_recorded(node_features, plan, edge_index)
@@ -194,7 +198,7 @@ class HyperGNN(nn.Module):
         grad = wants_grad(self, node_features)
         self._check_dropout()
         device = node_features.device
-        plan = self.plan_for(edge_index, edge_texts, node_features.size(0), device)
+        plan = self.plan_for(edge_index, edge_texts, node_features.size(0), device, training=grad)
         if grad:
             return self._forward_recorded(node_features, plan, edge_index)
         return self.forward_planned(node_features, plan)

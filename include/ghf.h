@@ -168,7 +168,7 @@ int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
                  int64_t row0, int64_t rows, int d, float* h_out, void* stream);
 
 /* ---- wide hidden sizes: the relation-stationary message layer (csrc/message_rs.hip) ---------------------------------
- * For d % 128 == 0, 256 <= d <= 1024 (ghf_message_rs_supported; BASELINE config 5).  Same statement as
+ * For d % 128 == 0, 128 <= d <= 1024 (ghf_message_rs_supported; BASELINE config 5, and d = 128 with many relations).  Same statement as
  * ghf_message_layer_fwd, in two passes over a CSR plan (block_nodes == 1):
  *   ghf_edge_transform_fwd: Y[ypos[k]] = h[src[k]] W_msg[r] + bias[r] + h[dst[k]] W_self[r] for the edges k in RELATION order
  *       (src / dst / ypos [E] int64: the edge's ends and its position in destination order); slice_tab [nslices][3] int64 =

@@ -785,6 +785,29 @@ def test_wide_rows_forward_and_sharding(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_many_relations_take_the_relation_stationary_layer():
+    """Hidden 128 with 200 relations: the inference plan is a CSR plan for csrc/message_rs.hip (the block kernel's time grows
+    with the relation count), the plan of a forward that records gradients keeps the block geometry; both equal the oracle."""
+    d, N, E, R = 128, 900, 20000, 200
+    g = synth.make_kg(N, E, R, 16, seed=321, kind="uniform")
+    params = synth.hypergnn_params(32, 16, d, 2, seed=12, log_scale=-0.5, randomize_ln=True)
+    model = HyperGNN(32, 16, d, 2).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    x, ei, texts = torch.from_numpy(g.node_features).to(DEV), torch.from_numpy(g.edge_index).to(DEV), g.edge_texts()
+    ref = O.forward(params, g.node_features, g.edge_index, texts, variant="factorised").numpy()
+    model.eval()
+    with torch.no_grad():
+        out = model(x, ei, texts)
+    plan = model.plan_for(ei, texts, N, DEV)
+    assert plan.block_nodes == 1 and plan.rs is not None
+    assert_close(out.cpu().numpy(), ref, "hidden 128, 200 relations, inference")
+    rec = model(x, ei, texts)                                           # parameters require grad: recorded forward
+    assert rec.requires_grad and model.plan_for(ei, texts, N, DEV, training=True).block_nodes > 1
+    assert_close(rec.detach().cpu().numpy(), ref, "hidden 128, 200 relations, recorded")
+    rec.sum().backward()
+    assert all(p.grad is not None for p in model.parameters())
+
+
 def test_the_binding_shown_in_integration_md_runs():
     """INTEGRATION.md §2 is executable: its three code blocks, pasted onto modules that hold the reference's parameters
     under the reference's attribute names, reproduce the golden outputs through the C ABI alone."""
