@@ -18,6 +18,7 @@
 // same k-permutation on both operands).
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace ghf {
@@ -126,15 +127,20 @@ __global__ __launch_bounds__(256) void edge_transform_kernel(
 // buffered.  fp32 MFMA: 64 MFMAs x 32 cycles per 16 k; here 48 x 16 cycles per 32 k — 5.3 x less matrix time.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int RS_KH = 32;
-
-__global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
+// KH = k per step: 32 (64-byte pieces of a row per visit; two workgroups per CU) or, for d % 256 == 0, 64 (whole 128-byte
+// lines, a half-row in four visits instead of eight; 129 KB of LDS, one workgroup per CU, the 16-byte granules of a row
+// XOR-swizzled by row & 7 so that a fragment read of 16 rows covers all banks).
+template <int KH>
+__global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
     const char* __restrict__ h_split, int64_t N, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
     const int64_t* __restrict__ ypos, const int64_t* __restrict__ slice_tab, const char* __restrict__ w2h, int R,
     const float* __restrict__ bias, float* __restrict__ Y) {
-    __shared__ __attribute__((aligned(16))) _Float16 At[2][2][RS_TM][RS_KH];      // [buffer][piece][row][k]
-    __shared__ __attribute__((aligned(16))) _Float16 Bt[2][2][RS_TN][RS_KH];
-    __shared__ float rsc[2][RS_TM];                                                // 2^-s of a tile row's source / destination row
+    constexpr int RS_KH = KH, GR = KH / 8, GPT = KH / 16;  // granules (8 fp16) per tile row; per thread, piece and step
+    extern __shared__ __attribute__((aligned(16))) char rs_lds[];
+    typedef _Float16 (*tile_t)[2][RS_TM][KH];              // [buffer][piece][row][k]
+    tile_t At = (tile_t)rs_lds, Bt = (tile_t)(rs_lds + (size_t)2 * 2 * RS_TM * KH * 2);
+    float (*rsc)[RS_TM] = (float (*)[RS_TM])(rs_lds + (size_t)2 * 2 * 2 * RS_TM * KH * 2);   // 2^-s of a tile row's source / destination row
+    auto swz = [](int row, int g) { return KH == 64 ? (g ^ (row & 7)) : g; };
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     const unsigned ncol = (unsigned)d / RS_TN, tile = blockIdx.x / ncol;
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
     const int n0 = (int)(blockIdx.x % ncol) * RS_TN;
     const size_t hrow = (size_t)4 * d;                     // bytes per split row
     const float* __restrict__ hscale = (const float*)(h_split + (size_t)N * hrow);
-    // staging map: thread t moves the 16-byte granules (row t/2, k 8 (2 (t%2) + i) .. +7), i = 0, 1, of both pieces
-    const int srow = t >> 1, sg = 2 * (t & 1);
+    // staging map: thread t moves the 16-byte granules (row t/2, k 8 (GPT (t%2) + i) .. +7), i < GPT, of both pieces
+    const int srow = t >> 1, sg = GPT * (t & 1);
     int64_t e = e0 + srow;
     if (e >= e1) e = e1 - 1;                               // rows past the tile's end repeat its last edge (never stored)
     const int64_t su = src[e], sv = dst[e];
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
     // Four register sets: the rows of a step are requested three steps before they are written to LDS — this kernel's 293
     // registers leave one wave per SIMD, so a gather's latency (an HBM miss, ~2 us) has to be covered by this wave's own
     // MFMAs (768 cycles per step).
-    struct Stage { i32x4 a[2][2], b[2][2]; };              // [piece][i]
+    struct Stage { i32x4 a[2][GPT], b[2][GPT]; };          // [piece][i]
     Stage st[4];
     auto fetch = [&](int k0, Stage& S) {                   // k0: first contraction index of the step, in [0, 2d)
         const int half = k0 >= d;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < GPT; ++i) {
                 S.a[pl][i] = *(const i32x4*)(arow + (size_t)pl * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
                 S.b[pl][i] = *(const i32x4*)(brow + (size_t)pl * d * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
             }
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *(i32x4*)&At[buf][pl][srow][8 * (sg + i)] = S.a[pl][i];
-                *(i32x4*)&Bt[buf][pl][srow][8 * (sg + i)] = S.b[pl][i];
+            for (int i = 0; i < GPT; ++i) {
+                *(i32x4*)&At[buf][pl][srow][8 * swz(srow, sg + i)] = S.a[pl][i];
+                *(i32x4*)&Bt[buf][pl][srow][8 * swz(srow, sg + i)] = S.b[pl][i];
             }
     };
 
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int half_steps = d / RS_KH, total = 2 * half_steps;              // (d % 128 == 0: half_steps % 4 == 0)
+    const int half_steps = d / RS_KH, total = 2 * half_steps;              // (half_steps % 4 == 0: d % 128 == 0, d % 256 == 0 for KH = 64)
     fetch(0, st[0]);
     fetch(1 * RS_KH, st[1]);
     fetch(2 * RS_KH, st[2]);
@@ -199,30 +205,39 @@ __global__ __launch_bounds__(256, 2) void edge_transform_h_kernel(
             const int buf = step & 1;
             const int pre = step + 3 < total ? step + 3 : total - 1;       // (past the end: the last step again, no branch around loads)
             fetch(pre * RS_KH, st[(i4 + 3) & 3]);
-            i32x4 a[2][2];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[rt][pl] = *(const i32x4*)&At[buf][pl][32 * w + 16 * rt + c16][8 * q];
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {               // the column tiles in two groups of four: 32 fragment registers live, not 64
-                i32x4 b[4][2];
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) b[c4][pl] = *(const i32x4*)&Bt[buf][pl][16 * (4 * ch + c4) + c16][8 * q];
+            for (int kk = 0; kk < KH / 32; ++kk) {
+                i32x4 a[2][2];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const int ct = 4 * ch + c4;
-                        auto fma = [&](int pa, int pb) {
-                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt][pa]),
-                                                                                 __builtin_bit_cast(f16x8, b[c4][pb]), acc[rt][ct], 0, 0, 0);
-                        };
-                        fma(1, 0); fma(0, 1);              // lo*hi, hi*lo
-                        fma(0, 0);                         // hi*hi
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const int row = 32 * w + 16 * rt + c16;
+                        a[rt][pl] = *(const i32x4*)&At[buf][pl][row][8 * swz(row, 4 * kk + q)];
                     }
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {           // the column tiles in two groups of four: 32 fragment registers live, not 64
+                    i32x4 b[4][2];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            const int row = 16 * (4 * ch + c4) + c16;
+                            b[c4][pl] = *(const i32x4*)&Bt[buf][pl][row][8 * swz(row, 4 * kk + q)];
+                        }
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const int ct = 4 * ch + c4;
+                            auto fma = [&](int pa, int pb) {
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt][pa]),
+                                                                                     __builtin_bit_cast(f16x8, b[c4][pb]), acc[rt][ct], 0, 0, 0);
+                            };
+                            fma(1, 0); fma(0, 1);          // lo*hi, hi*lo
+                            fma(0, 0);                     // hi*hi
+                        }
+                }
             }
             commit(buf ^ 1, st[(i4 + 1) & 3]);
             __syncthreads();
@@ -433,8 +448,21 @@ int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t
     // (one-dimensional grid, the column tile the fast index: the workgroups that share a tile's rows run side by side
     // and share them in L2)
     GHF_REQUIRE(nslices * (d / RS_TN) < (1ll << 31), "edge_transform: too many tiles per launch");
-    edge_transform_h_kernel<<<(unsigned)(nslices * (d / RS_TN)), 256, 0, stream>>>(
-        (const char*)h_split, N, d, src, dst, ypos, slice_tab, (const char*)w2h, R, bias, Y);
+    const unsigned grid = (unsigned)(nslices * (d / RS_TN));
+    // K-steps of 64 (whole 128-byte lines per visit, one workgroup per CU) measured 17.9 ms against 13.2 ms for K-steps of
+    // 32 (two workgroups per CU) on one GPU's share of C5: occupancy beats line efficiency here.  GHF_RS_K=64 for A/B.
+    static const bool k64 = getenv("GHF_RS_K") && atoi(getenv("GHF_RS_K")) == 64;
+    if ((d % 256) == 0 && k64) {
+        constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 64 * 2 + 2 * RS_TM * 4;
+        GHF_SET_MAX_LDS(edge_transform_h_kernel<64>, lds);
+        edge_transform_h_kernel<64><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
+                                                              (const char*)w2h, R, bias, Y);
+    } else {
+        constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 32 * 2 + 2 * RS_TM * 4;
+        GHF_SET_MAX_LDS(edge_transform_h_kernel<32>, lds);
+        edge_transform_h_kernel<32><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
+                                                              (const char*)w2h, R, bias, Y);
+    }
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
