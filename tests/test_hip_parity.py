@@ -785,6 +785,26 @@ def test_wide_rows_forward_and_sharding(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_training_at_hidden_256():
+    """A hidden size without destination-block kernels still trains (CSR plan, generic kernels in the recorded forward and
+    the backward): every gradient against autograd through the float64 oracle."""
+    d, N, E, R = 256, 200, 800, 5
+    g = synth.make_kg(N, E, R, 16, seed=77, kind="powerlaw")
+    params = synth.hypergnn_params(32, 16, d, 2, seed=3, log_scale=-0.5, randomize_ln=True)
+    model = HyperGNN(32, 16, d, 2).to(DEV).train()
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    x, ei, texts = torch.from_numpy(g.node_features).to(DEV), torch.from_numpy(g.edge_index).to(DEV), g.edge_texts()
+    gout = synth.normal(5, "g256", (N, d))
+    out = model(x, ei, texts)
+    (out * torch.from_numpy(gout).to(DEV)).sum().backward()
+    ref_p = {k: torch.from_numpy(np.ascontiguousarray(v)).double().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(ref_p, torch.from_numpy(g.node_features).double(), g.edge_index, texts, variant="factorised", dtype=torch.float64)
+    (ref * torch.from_numpy(gout).double()).sum().backward()
+    assert_close(out.detach().cpu().numpy(), ref.detach().float().numpy(), "hidden 256, recorded forward")
+    for k, p in model.named_parameters():
+        _grad_check(k, p.grad.cpu().numpy(), ref_p[k].grad.numpy())
+
+
 def test_many_relations_take_the_relation_stationary_layer():
     """Hidden 128 with 200 relations: the inference plan is a CSR plan for csrc/message_rs.hip (the block kernel's time grows
     with the relation count), the plan of a forward that records gradients keeps the block geometry; both equal the oracle."""
