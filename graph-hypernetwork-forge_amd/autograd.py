@@ -31,7 +31,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _native
-from .plan import GraphPlan, build_plan
+from .plan import GraphPlan, build_plan, build_rs
 
 
 @dataclass
@@ -91,11 +91,23 @@ def _layer_weights(plan: GraphPlan, Wm: Optional[torch.Tensor], Ws: Optional[tor
     return _native.weights_pack(Wm, Ws, transpose, R, d, plan.wlayout), None
 
 
-def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor) -> torch.Tensor:
+def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, flags: int) -> torch.Tensor:
+    """A message pass without tail (NO_TAIL / RAW_SUM) on the plan's kernel: the destination-block or generic kernel, or —
+    CSR plans of wide rows — the relation-stationary layer."""
     out = torch.empty_like(x)
-    _native.message_layer_fwd(x, plan, W, W_self, zero_bias, plan.wlayout, None, None, 0.0, out,
-                              flags=_native.GHF_FLAG_RAW_SUM)
+    if plan.block_nodes == 1 and _native.rs_supported(x.size(1)) and plan.E > 0:
+        if plan.rs is None:
+            plan.rs = build_rs(plan)
+        Y = plan.rs.scratch(plan.E, x.size(1), x.device)
+        _native.edge_transform_fwd(x, plan.rs, W, W_self, bias, Y)
+        _native.segment_tail_fwd(Y, plan.rs, None, None, None, 0.0, out, flags=flags)
+        return out
+    _native.message_layer_fwd(x, plan, W, W_self, bias, plan.wlayout, None, None, 0.0, out, flags=flags)
     return out
+
+
+def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor) -> torch.Tensor:
+    return _message(x, plan, W, W_self, zero_bias, _native.GHF_FLAG_RAW_SUM)
 
 
 class MessageLayerFn(torch.autograd.Function):
@@ -106,9 +118,7 @@ class MessageLayerFn(torch.autograd.Function):
         plan = tp.fwd
         h = h.contiguous()
         W, W2 = _layer_weights(plan, W_msg.detach(), W_self.detach(), transpose=False)
-        agg = torch.empty_like(h)
-        _native.message_layer_fwd(h, plan, W, W2, bias.detach().contiguous(), plan.wlayout, None, None, 0.0, agg,
-                                  flags=_native.GHF_FLAG_NO_TAIL)
+        agg = _message(h, plan, W, W2, bias.detach().contiguous(), _native.GHF_FLAG_NO_TAIL)
         out = torch.empty_like(h)
         _native.tail_fwd(agg, h, gamma.detach(), beta.detach(), eps, out)
         ctx.save_for_backward(h, agg, W_msg, W_self, gamma)
