@@ -37,10 +37,10 @@ def main():
     dev = torch.device("cuda", 0)
     worst_f = worst_b = 0.0
     for case in range(args.cases):
-        d = int(rng.choice([16, 20, 32, 64, 128, 128, 128, 256]))
+        d = int(rng.choice([16, 20, 32, 64, 128, 128, 128, 256, 384]))
         N = int(rng.integers(1, 2500))
         E = int(rng.integers(1, 20000 if d < 256 else 4000))
-        R = int(rng.integers(1, 40))
+        R = int(rng.integers(1, 40)) if rng.random() < 0.8 else int(rng.integers(128, 220))   # many relations: the relation-stationary layer at 128
         L = int(rng.integers(1, 4))
         T = int(rng.choice([16, 32, 64]))
         F = int(rng.choice([8, 16, d]))
@@ -68,7 +68,7 @@ def main():
         ef = rel_l2(out, ref)
         ok = np.allclose(out, ref, rtol=1e-4, atol=1e-5) and ef < 1e-5
         eb = 0.0
-        if not args.no_backward and d != 256:
+        if not args.no_backward and d < 256:
             model.train()
             model.zero_grad()
             gout = synth.normal(seed % 977, "fz", (N, d))
@@ -92,7 +92,20 @@ def main():
                     print(f"            {k:50s} {e:.2e}  (float32 oracle {rel_l2(ref_q[k].grad.numpy(), gw):.2e})  |g| {np.linalg.norm(gw):.3e}")
                 if e > eb:
                     eb, kb, floor = e, k, rel_l2(ref_q[k].grad.numpy(), gw)
-            ok = ok and eb < max(2e-4, 10 * floor)
+            ok_b = eb < max(2e-4, 10 * floor)
+            if not ok_b:
+                # A ReLU kink?  Re-differentiate the float64 oracle with the parameters moved by one float32 ulp's worth of
+                # noise: if ITS gradient of that parameter moves as much, a pre-activation sits within rounding of zero
+                # and no float32 implementation can be expected to land on the oracle's side of it.
+                nz = np.random.default_rng(seed)
+                pert = {k: v * (1.0 + 1e-7 * nz.standard_normal(v.shape)).astype(v.dtype) for k, v in params.items()}
+                ref_k = {k: torch.from_numpy(np.ascontiguousarray(v)).double().requires_grad_(True) for k, v in pert.items()}
+                rk = O.forward(ref_k, torch.from_numpy(g.node_features).double(), ei, texts, variant="factorised", dtype=torch.float64)
+                (rk * torch.from_numpy(gout).double()).sum().backward()
+                kink = rel_l2(ref_k[kb].grad.numpy(), ref_p[kb].grad.numpy())
+                print(f"         the float64 oracle's own gradient of {kb} moves by {kink:.2e} under 1e-7 relative noise on the parameters")
+                ok_b = kink > 0.1 * eb                      # ill-conditioned instance: not a finding
+            ok = ok and ok_b
             if eb > 2e-5:
                 print(f"         worst gradient: {kb} ({eb:.2e}; float32 autograd of the oracle itself: {floor:.2e})")
         worst_f, worst_b = max(worst_f, ef), max(worst_b, eb)

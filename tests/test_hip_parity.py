@@ -578,7 +578,8 @@ def _grad_check(name, got, want, rtol=2e-4, l2=5e-5):
 
 
 @pytest.mark.parametrize("T,Hh,nh,d_in,d_out,R", [(32, 64, 2, 16, 16, 7), (64, 128, 2, 128, 128, 5), (16, 40, 1, 8, 24, 3),
-                                                  (16, 32, 0, 8, 8, 4), (32, 64, 3, 20, 20, 1)])
+                                                  (16, 32, 0, 8, 8, 4), (32, 64, 3, 20, 20, 1), (64, 128, 2, 20, 20, 187),
+                                                  (32, 64, 2, 16, 16, 600)])
 def test_weight_generator_backward_matches_autograd_of_the_oracle(T, Hh, nh, d_in, d_out, R):
     """Reference tests/test_weight_generator.py:86-106 (gradient reaches the embedding, the scales train) made exact: every
     gradient of WeightGenerator.forward against torch.autograd through the oracle, in float64."""
