@@ -118,7 +118,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GHF_DIST_BACKEND", "nccl")          # "gloo": rehearsal of the multi-rank path on one card
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from graph_hypernetwork_forge_amd import HyperGNN, _native, synth
     from graph_hypernetwork_forge_amd.dist import ShardedHyperGNN
