@@ -65,7 +65,7 @@ SIGNATURES = {
     "ghf_weights_pack_rs": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "ghf_edge_transform_h_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "ghf_segment_partial_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
-    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _i32, _vp]),
+    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
     "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
@@ -335,9 +335,11 @@ def rs_exact() -> bool:
     return os.environ.get("GHF_KERNEL") == "rs32"
 
 
-def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor,
+                       h_split: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Pass 1: per-edge results into Y [E, d] at the edges' destination-order positions (rs: plan.RsPlan; W_msg / W_self
-    natural [R, d, d]).  Cuts h and the weights into their two fp16 pieces first (or transposes the weights, rs32)."""
+    natural [R, d, d]).  Cuts the weights and — unless the caller has them (`h_split`, from the previous layer's pass 2) —
+    the rows of h into their two fp16 pieces first (or transposes the weights, rs32)."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
@@ -349,7 +351,7 @@ def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.T
                                           rs.slice_tab.size(0), _ptr(WmT), _ptr(WsT),
                                           _ptr(_req(bias, torch.float32, "bias")), _ptr(Y), _stream()), "ghf_edge_transform_fwd")
     else:
-        hs = split_rows(h, WLAYOUT_SPLIT2H)
+        hs = h_split if h_split is not None else split_rows(h, WLAYOUT_SPLIT2H)
         w2h = torch.empty(lib.ghf_weights_rs_bytes(R, d), dtype=torch.uint8, device=h.device)
         shift = torch.empty(R, dtype=torch.int32, device=h.device)
         _check(lib.ghf_weights_pack_rs(_ptr(Wm), _ptr(Ws), R, d, _ptr(w2h), _ptr(shift), _stream()), "ghf_weights_pack_rs")
@@ -363,14 +365,16 @@ def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.T
 
 
 def segment_tail_fwd(Y: torch.Tensor, rs, h: Optional[torch.Tensor], ln_gamma, ln_beta, ln_eps: float, h_out: torch.Tensor,
-                     row0: int = 0, rows: Optional[int] = None, flags: int = 0) -> torch.Tensor:
-    """Pass 2: destination sums of Y, mean and tail for rows [row0, row0+rows)."""
+                     row0: int = 0, rows: Optional[int] = None, flags: int = 0,
+                     h_split_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Pass 2: destination sums of Y, mean and tail for rows [row0, row0+rows); `h_split_out` (alloc_split(N, d, SPLIT2H))
+    also receives the rows in the form the next layer's pass 1 gathers."""
     N, d = h_out.shape
     rows = N - row0 if rows is None else rows
     P = rs.hub_scratch(d) if rs.hub_of is not None else None      # filled by edge_transform_fwd
     _check(load().ghf_segment_tail_fwd(_ptr(Y), _ptr(rs.off), _ptr(rs.hub_of), _ptr(rs.hub_tab), _ptr(P), _ptr(h), _ptr(ln_gamma),
-                                       _ptr(ln_beta), float(ln_eps), row0, rows, d, _ptr(h_out), flags, _stream()),
-           "ghf_segment_tail_fwd")
+                                       _ptr(ln_beta), float(ln_eps), row0, rows, d, _ptr(h_out), _ptr(h_split_out), N, flags,
+                                       _stream()), "ghf_segment_tail_fwd")
     return h_out
 
 

@@ -230,12 +230,13 @@ int ghf_segment_partial_fwd(const float* Y, const int64_t* hub_chunks, int64_t n
 
 int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                          const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0,
-                         int64_t rows, int d, float* h_out, int flags, void* stream) {
+                         int64_t rows, int d, float* h_out, void* h_split_out, int64_t n_split, int flags, void* stream) {
     GHF_REQUIRE(Y && off && h_out, "segment_tail_fwd: null pointer argument");
     GHF_REQUIRE(!hub_of || (hub_tab && P), "segment_tail_fwd: hub_of without hub_tab / P");
     GHF_REQUIRE((flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM)) || (h && ln_gamma && ln_beta), "segment_tail_fwd: tail inputs missing");
-    return launch_segment_tail(Y, off, hub_of, hub_tab, P, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, flags,
-                               (hipStream_t)stream);
+    GHF_REQUIRE(!h_split_out || n_split >= row0 + rows, "segment_tail_fwd: h_split_out has fewer rows than the range written");
+    return launch_segment_tail(Y, off, hub_of, hub_tab, P, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, h_split_out,
+                               n_split, flags, (hipStream_t)stream);
 }
 
 int ghf_edge_outer_supported(int d) { return edge_outer_supported(d); }

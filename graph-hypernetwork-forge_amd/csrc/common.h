@@ -191,7 +191,7 @@ int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t
 int launch_segment_partial(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, hipStream_t stream);
 int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                         const float* h, const float* g, const float* b, float eps, int64_t row0, int64_t rows, int d,
-                        float* h_out, int flags, hipStream_t stream);
+                        float* h_out, void* h_split_out, int64_t n_split, int flags, hipStream_t stream);
 int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream);
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
                           float* acts, hipStream_t stream);

@@ -359,7 +359,8 @@ template <int CPL>
 __global__ __launch_bounds__(256) void segment_tail_kernel(
     const float* __restrict__ Y, const int64_t* __restrict__ off, const int32_t* __restrict__ hub_of,
     const int64_t* __restrict__ hub_tab, const float* __restrict__ P, const float* __restrict__ h, const float* __restrict__ g,
-    const float* __restrict__ b, float eps, int64_t row0, int64_t row_end, float* __restrict__ h_out, int no_tail) {
+    const float* __restrict__ b, float eps, int64_t row0, int64_t row_end, float* __restrict__ h_out,
+    char* __restrict__ h_split_out, int64_t n_split, int no_tail) {
     constexpr int d = 64 * CPL;
     const int lane = threadIdx.x & 63;
     const int64_t v = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -412,6 +413,22 @@ __global__ __launch_bounds__(256) void segment_tail_kernel(
     }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) h_out[(size_t)v * d + lane + 64 * c] = x[c];
+    if (h_split_out) {                                     // the same row cut into its two fp16 pieces, for the next layer's pass 1
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) mx = fmaxf(mx, fabsf(x[c]));
+        const int sh = split2h_shift(wave_absmax(mx));
+        const float up = pow2f(sh);
+        _Float16* __restrict__ sp = (_Float16*)(h_split_out + (size_t)v * 4 * d);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            _Float16 hi, lo;
+            split2h(x[c] * up, hi, lo);
+            sp[lane + 64 * c] = hi;
+            sp[d + lane + 64 * c] = lo;
+        }
+        if (lane == 0) *(float*)(h_split_out + (size_t)n_split * 4 * d + (size_t)v * 4) = pow2f(-sh);
+    }
 }
 
 // (d = 128 runs too — GHF_KERNEL=rs selects it there for A/B — but the destination-block kernel is the default at 128)
@@ -478,7 +495,7 @@ int launch_segment_partial(const float* Y, const int64_t* hub_chunks, int64_t nc
 
 int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                         const float* h, const float* g, const float* b, float eps, int64_t row0, int64_t rows, int d,
-                        float* h_out, int flags, hipStream_t stream) {
+                        float* h_out, void* h_split_out, int64_t n_split, int flags, hipStream_t stream) {
     GHF_REQUIRE(message_rs_supported(d), "segment_tail: d = %d is not a relation-stationary width", d);
     if (rows <= 0) return GHF_OK;
     GHF_REQUIRE(cdiv(rows, 4) < (1ll << 31), "segment_tail: too many rows per launch");
@@ -487,7 +504,8 @@ int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_o
     switch (d / 64) {
 #define GHF_RS_CASE(CPL)                                                                                                        \
     case CPL:                                                                                                                   \
-        segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out, nt); \
+        segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out,    \
+                                                           (char*)h_split_out, n_split, nt);                                    \
         break;
         GHF_RS_CASE(2) GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)
 #undef GHF_RS_CASE

@@ -305,18 +305,27 @@ class HyperGNN(nn.Module):
             plan.rs = build_rs(plan)
         rs = plan.rs
         text_embs = self.text_encoder(plan.unique_texts, device)
-        h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach())
+        lo, hi = plan.row_lo, (plan.row_hi or plan.N)
+        # rows travel between the layers already cut into fp16 pieces (written by the input projection / pass 2's tail)
+        # when one process computes every row; the fp32 MFMA variant gathers h itself
+        pieces = exchange is None and lo == 0 and hi == plan.N and not _native.rs_exact()
+        hs = _native.alloc_split(plan.N, self.hidden_dim, _native.WLAYOUT_SPLIT2H, device) if pieces else None
+        hs_next = torch.empty_like(hs) if pieces else None
+        h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach(), h_split=hs,
+                                   split_layout=_native.WLAYOUT_SPLIT2H if pieces else 0)
         h_next = torch.empty_like(h)
         Y = rs.scratch(plan.E, self.hidden_dim, device)
-        lo, hi = plan.row_lo, (plan.row_hi or plan.N)
-        for gen, norm in zip(self.weight_generators, self.layer_norms):
+        last = len(self.layer_norms) - 1
+        for l, (gen, norm) in enumerate(zip(self.weight_generators, self.layer_norms)):
             W_msg, W_self, bias = gen.generate(text_embs, _native.WLAYOUT_NATURAL)
             if plan.E > 0:
-                _native.edge_transform_fwd(h, rs, W_msg, W_self, bias, Y)
-            _native.segment_tail_fwd(Y, rs, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo)
+                _native.edge_transform_fwd(h, rs, W_msg, W_self, bias, Y, h_split=hs)
+            _native.segment_tail_fwd(Y, rs, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo,
+                                     h_split_out=hs_next if pieces and l < last else None)
             if exchange is not None:
                 exchange(h_next)
             h, h_next = h_next, h
+            hs, hs_next = hs_next, hs
         return h
 
     # -- reference-internal seam kept for API parity (reference :160-230) ---------------------

@@ -182,7 +182,9 @@ int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
  *   ghf_segment_tail_fwd: rows [row0, row0+rows): out_v = sum(Y[off[v] .. off[v+1])) / max(indeg, 1), then the tail of
  *       ghf_tail_fwd (flags: GHF_FLAG_NO_TAIL / GHF_FLAG_RAW_SUM as for the message layer); off [N+1] int64.  Hubs:
  *       hub_of [N] int32 (hub index or -1; NULL = no hubs), hub_tab [H][2] int64 (first slot, slots) select rows of P
- *       to add instead of rows of Y; the mean still divides by off[v+1] - off[v]. */
+ *       to add instead of rows of Y; the mean still divides by off[v+1] - off[v].  h_split_out (optional): the rows
+ *       written, also in ghf_split_rows(.., GHF_WLAYOUT_SPLIT2H) form for the next layer's ghf_edge_transform_h_fwd — a buffer
+ *       of n_split rows (ghf_split_rows_bytes(n_split, d, GHF_WLAYOUT_SPLIT2H)). */
 size_t ghf_weights_rs_bytes(int R, int d);
 int ghf_weights_pack_rs(const float* W_msg, const float* W_self, int R, int d, void* w2h, int* shift_ws, void* stream);
 int ghf_edge_transform_h_fwd(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
@@ -195,7 +197,7 @@ int ghf_edge_transform_fwd(const float* h, int64_t N, int d, const int64_t* src,
                            float* Y, void* stream);
 int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                          const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0,
-                         int64_t rows, int d, float* h_out, int flags, void* stream);
+                         int64_t rows, int d, float* h_out, void* h_split_out, int64_t n_split, int flags, void* stream);
 
 /* ---- backward of the path (the reference trains through it with autograd: demo.py:79-101) ----------
  * With out_v = (1/c_v) sum_e(h_u Wm[r] + b[r] + h_v Ws[r]), x = relu(out + h), h' = LayerNorm(x), g' = dL/dh':

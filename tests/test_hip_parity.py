@@ -738,8 +738,10 @@ def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, exact, monkeypatch):
     agg = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
     ref = O.layer_tail(agg, th(h), th(gamma), th(beta))
     out = torch.empty(N, d, device=DEV)
-    _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, out)
+    hs_out = _native.alloc_split(N, d, _native.WLAYOUT_SPLIT2H, DEV)
+    _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, out, h_split_out=hs_out)
     assert_close(out.cpu().numpy(), ref.numpy(), "wide-row layer")
+    assert torch.equal(hs_out, _native.split_rows(out, _native.WLAYOUT_SPLIT2H)), "pass 2's pieces = ghf_split_rows of its rows"
     again = torch.empty_like(out)
     _native.edge_transform_fwd(t(h), rs, t(Wm), t(Ws), t(b), Y)
     _native.segment_tail_fwd(Y, rs, t(h), t(gamma), t(beta), 1e-5, again)
