@@ -1,4 +1,7 @@
-from .weight_generator import WeightGenerator
-from .hypergnn import HyperGNN, TextEncoder
+"""Host mirrors of the reference's modules (same constructors, attributes, state_dict keys and call signatures); every
+forward and backward runs in libghf_hip.so."""
 
-__all__ = ["WeightGenerator", "HyperGNN", "TextEncoder"]
+from .hypergnn import GraphedForward, HyperGNN, TextEncoder
+from .weight_generator import WeightGenerator
+
+__all__ = ("HyperGNN", "WeightGenerator", "TextEncoder", "GraphedForward")
