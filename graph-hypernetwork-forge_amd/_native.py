@@ -447,7 +447,8 @@ def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.T
     lib = load()
     h, G = _req(h, torch.float32, "h"), _req(G, torch.float32, "G")
     d, ns = h.size(1), slice_tab.size(0)
-    ws = torch.empty(ns * (2 * d * d + d), dtype=torch.float32, device=h.device)
+    D = min(d, 128)
+    ws = torch.empty(ns * (2 * D * D + D), dtype=torch.float32, device=h.device)
     dW = torch.empty(R, 2 * d, d, dtype=torch.float32, device=h.device)
     db = torch.empty(R, d, dtype=torch.float32, device=h.device)
     _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), _ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")),

@@ -189,8 +189,12 @@ __global__ __launch_bounds__(256) void group_outer_kernel(const float* __restric
 constexpr int EO_ET = 32;                                 // edges per tile
 
 template <int D>
+// Wider rows (d % 128 == 0) run the D = 128 instance once per [256, 128] tile of the [2d, d] gradient: ia / ib name the
+// rows (sources or destinations) and xa_col / xb_col the two 128-column pieces of them that make the tile's 256 rows, g_col
+// the tile's 128 columns of G (always indexed by destination), ld = d the row stride of h and G.
 __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kernel(
-    const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+    const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+    const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
     const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b) {
     constexpr int RG = 2 * D / 64, CG = D / 64, NT = RG * CG * 64;
     constexpr int F4 = D / 4;                             // float4 per row of h / G
@@ -214,14 +218,15 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
     float bsum = 0.f;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int64_t is[LPR], id[LPR];                             // indices of the tile to gather next
+    int64_t is[LPR], iv[LPR], id[LPR];                    // indices of the tile to gather next
     f32x4 st[3][LPR];                                     // its rows on their way to LDS
     auto load_idx = [&](int tile) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
             const int64_t e = e0 + (int64_t)tile * EO_ET + (t + NT * j) / F4;
             const bool ok = e < e1;
-            is[j] = ok ? src[e] : -1;
+            is[j] = ok ? ia[e] : -1;
+            iv[j] = ok ? ib[e] : -1;
             id[j] = ok ? dst[e] : -1;
         }
     };
@@ -230,9 +235,9 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
         for (int j = 0; j < LPR; ++j) {
             const int c4 = (t + NT * j) % F4;
             const bool ok = is[j] >= 0;
-            st[0][j] = ok ? *(const f32x4*)(h + (size_t)is[j] * D + 4 * c4) : zero4;
-            st[1][j] = ok ? *(const f32x4*)(h + (size_t)id[j] * D + 4 * c4) : zero4;
-            st[2][j] = ok ? *(const f32x4*)(G + (size_t)id[j] * D + 4 * c4) : zero4;
+            st[0][j] = ok ? *(const f32x4*)(h + (size_t)is[j] * ld + xa_col + 4 * c4) : zero4;
+            st[1][j] = ok ? *(const f32x4*)(h + (size_t)iv[j] * ld + xb_col + 4 * c4) : zero4;
+            st[2][j] = ok ? *(const f32x4*)(G + (size_t)id[j] * ld + g_col + 4 * c4) : zero4;
         }
     };
     auto commit = [&](int buf) {
@@ -295,51 +300,65 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
     }
 }
 
-// dW[r] = sum of its slices' partial products in slice order (x: float4 of the [2D*D] matrix, y: relation); db likewise
+// dW[r] tile = sum of its slices' partial products in slice order (x: float4 of the [2D, D] tile, y: relation); db likewise.
+// The tile sits at (row0, col0) of the relation's [2d, d] matrix (row0 = col0 = 0, D = d for the single-tile sizes).
 __global__ __launch_bounds__(256) void edge_outer_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
-                                                                const int64_t* __restrict__ slice_off, int d,
-                                                                float* __restrict__ dW, float* __restrict__ db) {
+                                                                const int64_t* __restrict__ slice_off, int D, int d, int row0,
+                                                                int col0, float* __restrict__ dW, float* __restrict__ db) {
     const int r = blockIdx.y;
     const int64_t s0 = slice_off[r], s1 = slice_off[r + 1];
-    const int n4 = 2 * d * d / 4;
+    const int n4 = 2 * D * D / 4;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n4) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int64_t k = s0; k < s1; ++k) s += *(const f32x4*)(partial + (size_t)k * 2 * d * d + 4 * (size_t)i);
-        *(f32x4*)(dW + (size_t)r * 2 * d * d + 4 * (size_t)i) = s;
-    } else if (i - n4 < d) {
+        for (int64_t k = s0; k < s1; ++k) s += *(const f32x4*)(partial + (size_t)k * 2 * D * D + 4 * (size_t)i);
+        const int row = (4 * i) / D, col = (4 * i) % D;
+        *(f32x4*)(dW + ((size_t)r * 2 * d + row0 + row) * d + col0 + col) = s;
+    } else if (i - n4 < D && db) {
         float s = 0.f;
-        for (int64_t k = s0; k < s1; ++k) s += partial_b[(size_t)k * d + (i - n4)];
-        db[(size_t)r * d + (i - n4)] = s;
+        for (int64_t k = s0; k < s1; ++k) s += partial_b[(size_t)k * D + (i - n4)];
+        db[(size_t)r * d + col0 + (i - n4)] = s;
     }
 }
 
 template <int D>
-static int edge_outer_launch(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
-                             int64_t nslices, float* partial, float* partial_b, hipStream_t stream) {
+static int edge_outer_launch(const float* h, const float* G, const int64_t* ia, const int64_t* ib, const int64_t* dst, int xa_col,
+                             int xb_col, int g_col, int ld, const int64_t* slice_tab, int64_t nslices, float* partial,
+                             float* partial_b, hipStream_t stream) {
     constexpr int NT = (2 * D / 64) * (D / 64) * 64;
     const size_t lds = (size_t)2 * EO_ET * 3 * D * sizeof(float);
     GHF_SET_MAX_LDS(edge_outer_kernel<D>, lds);
-    edge_outer_kernel<D><<<(unsigned)nslices, NT, lds, stream>>>(h, G, src, dst, slice_tab, partial, partial_b);
+    edge_outer_kernel<D><<<(unsigned)nslices, NT, lds, stream>>>(h, G, ia, ib, dst, xa_col, xb_col, g_col, ld, slice_tab, partial,
+                                                                 partial_b);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
 
-int edge_outer_supported(int d) { return d == 64 || d == 128; }
+int edge_outer_supported(int d) { return d == 64 || (d >= 128 && d <= BW_MAX_D && (d % 128) == 0); }
 
 int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                       const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
                       hipStream_t stream) {
-    GHF_REQUIRE(edge_outer_supported(d), "edge_outer: d = %d has no tile (64 and 128 do; use ghf_group_outer)", d);
+    GHF_REQUIRE(edge_outer_supported(d), "edge_outer: d = %d has no tile (64 and multiples of 128 do; use ghf_group_outer)", d);
     GHF_REQUIRE(nslices > 0 && R > 0, "edge_outer: nothing to do");
+    const int D = d == 64 ? 64 : 128;                      // tile: [2D, D] of the relation's [2d, d] gradient
     float* partial = workspace;
-    float* partial_b = workspace + (size_t)nslices * 2 * d * d;
-    int rc = d == 128 ? edge_outer_launch<128>(h, G, src, dst, slice_tab, nslices, partial, partial_b, stream)
-                      : edge_outer_launch<64>(h, G, src, dst, slice_tab, nslices, partial, partial_b, stream);
-    if (rc != GHF_OK) return rc;
-    const unsigned gx = (unsigned)cdiv((int64_t)2 * d * d / 4 + d, 256);
-    edge_outer_reduce_kernel<<<dim3(gx, (unsigned)R), 256, 0, stream>>>(partial, partial_b, slice_off, d, dW, db);
-    GHF_LAUNCH_CHECK();
+    float* partial_b = workspace + (size_t)nslices * 2 * D * D;
+    const unsigned gx = (unsigned)cdiv((int64_t)2 * D * D / 4 + D, 256);
+    for (int rb = 0; rb < d / D; ++rb)                     // tile rows 2D*rb ..: two D-column pieces of [h_src | h_dst]
+        for (int cb = 0; cb < d / D; ++cb) {
+            const int fa = 2 * rb * D, fb = fa + D;        // first stacked feature of the two pieces
+            const int64_t* ia = fa < d ? src : dst;
+            const int64_t* ib = fb < d ? src : dst;
+            int rc = D == 128 ? edge_outer_launch<128>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
+                                                       partial_b, stream)
+                              : edge_outer_launch<64>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
+                                                      partial_b, stream);
+            if (rc != GHF_OK) return rc;
+            edge_outer_reduce_kernel<<<dim3(gx, (unsigned)R), 256, 0, stream>>>(partial, partial_b, slice_off, D, d, 2 * rb * D, cb * D,
+                                                                               dW, rb == 0 ? db : nullptr);
+            GHF_LAUNCH_CHECK();
+        }
     return GHF_OK;
 }
 

@@ -222,12 +222,13 @@ int ghf_colsum(const float* X, const float* mask, int64_t N, int d, float* works
 int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void* stream);
 int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, const int64_t* ib, int db,
                     const int64_t* gstart, const int64_t* gend, int ngroups, float* C, int accumulate, void* stream);
-/* The three per-relation gradients of a layer in one pass over the edges (d = 64 or 128; ghf_edge_outer_supported):
+/* The three per-relation gradients of a layer in one pass over the edges (d = 64 or a multiple of 128, tile by tile;
+ * ghf_edge_outer_supported):
  *   dW[r] = sum_{e in r} [h[src[e]] | h[dst[e]]]^T G[dst[e]]   ([R][2d][d]: dW_msg[r] stacked on dW_self[r]),
  *   db[r] = sum_{e in r} G[dst[e]]                             ([R][d])
  * src / dst [E]: the edges grouped by relation (ghf_group_edges); slice_tab [nslices][3] = (relation, first edge, end edge)
  * cuts every relation's range into slices, relations ascending, never across a relation; slice_off [R+1] = first slice of
- * each relation.  workspace: nslices * (2*d*d + d) floats.  Exact fp32, fixed summation order. */
+ * each relation.  workspace: nslices * (2*D*D + D) floats, D = min(d, 128).  Exact fp32, fixed summation order. */
 int ghf_edge_outer_supported(int d);
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                    const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,

@@ -503,7 +503,8 @@ def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind)
         assert rel_l2 < 2e-5, f"d{name}: relative L2 {rel_l2:.3e}"
 
 
-@pytest.mark.parametrize("d,N,E,R", [(128, 700, 30000, 5), (64, 300, 9000, 3), (128, 50, 40, 4)])
+@pytest.mark.parametrize("d,N,E,R", [(128, 700, 30000, 5), (64, 300, 9000, 3), (128, 50, 40, 4), (256, 400, 12000, 4),
+                                     (384, 150, 3000, 3)])
 def test_edge_outer_matches_the_plain_contraction(d, N, E, R):
     """ghf_edge_outer (all three per-relation gradients in one pass over sliced relation groups) against the same sums in
     float64, including relations without edges, slices shorter than a tile and a hub destination."""
