@@ -43,6 +43,11 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
         *wlayout = GHF_WLAYOUT_NATURAL;
         *chunk_rows = 0;
         *split_chunks = 0;
+    } else if (kv && !strcmp(kv, "bx") && message_bx_config(d, &bn, &cr, &sc)) {
+        *block_nodes = bn;
+        *wlayout = GHF_WLAYOUT_SPLIT2H;
+        *chunk_rows = cr;
+        *split_chunks = sc;
     } else if ((!kv || !strcmp(kv, "hx")) && message_hx_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_SPLIT2H;
@@ -164,6 +169,7 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
               ln_gamma, ln_beta, ln_eps, row0, rows, h_out, h_split_out, flags};
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
+    if (wlayout == GHF_WLAYOUT_SPLIT2H && message_bx_owns(d, block_nodes)) return launch_message_bx(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_message_hx(a, (hipStream_t)stream);
     return launch_message_mfma(a, (hipStream_t)stream);
 }

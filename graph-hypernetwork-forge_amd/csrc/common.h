@@ -153,6 +153,9 @@ int launch_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t r
 int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
 int launch_message_hx(const MsgArgs& a, hipStream_t stream);       // fp16 two-piece contraction (d = 128), SPLIT2H weights
 bool message_hx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
+int launch_message_bx(const MsgArgs& a, hipStream_t stream);       // the same contraction, block sums in registers (message_bx.hip)
+bool message_bx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
+bool message_bx_owns(int d, int block_nodes);                      // whether a SPLIT2H plan of this geometry is message_bx's
 int launch_message_generic(const MsgArgs& a, hipStream_t stream);
 int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
 int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)

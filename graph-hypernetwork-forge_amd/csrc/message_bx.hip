@@ -1,0 +1,672 @@
+// message_bx.hip — K2+K3 for hidden 128 with the block sums in REGISTERS (reference: models/hypergnn.py:201-230, 288-296).
+//
+// message_hx.hip keeps a destination block's fp32 sums in LDS, which caps the block at 216 nodes; a (block, relation)
+// chunk then has ~34 rows at C3 and the relation's 128 KB of weights is pulled through the CU's 64 B/clk vector-memory
+// path once per 34 rows (38 GB per launch: profiles/r01_message_kernel_pmc.json).  The register file of a CU is 512 KB
+// against 160 KB of LDS, and most of it was idle.  Here:
+//
+//   * the block is BN = 384 nodes (chunks of ~60 rows: 1.8x the rows per weight fetch, 0.56x the chunks);
+//   * waves 4-7 (HELPERS) own the block sums: lane l of helper wave hw holds U "units" of UW consecutive sum positions of
+//     a node — unit u = U*l + k is part (u % NU) of node 96*hw + u / NU, NU = 128 / UW — as plain VGPRs with compile-time
+//     indices (192 registers per lane at BN = 384);
+//   * waves 0-3 (CONSUMERS) run the contraction exactly as message_hx.hip does (same SPLIT2H weights, same row pieces,
+//     three v_mfma_f32_16x16x32_f16 per product, B fragments in a register ring refilled straight from L2) and write a
+//     chunk's finished rows Y [rows][128] fp32 to an LDS staging tile instead of scattering them;
+//   * the helpers FOLD the staged rows into their registers: a table node -> row (written per chunk) tells every owner
+//     lane which staged row, if any, belongs to its node; it reads that row's part with ds_read_b128 and adds it.  Rows
+//     of one chunk with equal destinations (a run; rows are sorted by destination) are first added into the run's last
+//     row by the wave that owns the destination, in ascending order.  No atomics, no dynamic register index, fixed
+//     order: bitwise reproducible;
+//   * the helpers gather the A tiles with LDS-DMA (buffer_load_dwordx4 ... lds, per-lane source address, 1 KiB per wave
+//     instruction, the XOR swizzle applied on the source side): no staging registers, no ds_write.  Source rows (HBM) are
+//     requested two stages ahead into one of two tiles, destination rows (L2) one stage ahead;
+//   * the fused tail runs from LDS after the helpers have dumped their registers there (two halves of 192 nodes).
+//
+// LDS (CR = 76 rows per chunk): P0a, P0b (source-row tiles), P1 (destination-row tile), Y (staging), 38,912 bytes each;
+// table [BN]; four chunk descriptors ("meta": the rows' scales and node ids).  A stage = one K-phase of one chunk; one
+// workgroup barrier per stage:
+//   stage (k,0)  consumers: phase 0 (h_src x W_msg) from P0[k&1]          helpers: DMA P1 <- dst rows of chunk k; fold Y(k-1)
+//   stage (k,1)  consumers: phase 1 (h_dst x W_self) from P1, write Y(k)   helpers: DMA P0[k&1] <- src rows of chunk k+2;
+//                                                                                   table of chunk k; descriptor of chunk k+3
+#include "common.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace ghf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <class T>
+__device__ __forceinline__ const T* bx_at(const void* base, uint32_t byte_off) {   // uniform base + 32-bit byte offset
+    return (const T*)((const char*)base + byte_off);
+}
+
+// LDS accesses of the helper waves go through inline asm: hipcc's s_waitcnt insertion orders every LDS read it can see
+// behind all outstanding LDS-DMA of the wave (vmcnt(0)), which would turn the two-stage prefetch into a blocking load.
+// An asm load's destination counts as written when the statement ends, so the wait must be in the same statement (or name
+// the destinations, as the fold's counted waits do): otherwise the compiler may read the register before the data lands.
+__device__ __forceinline__ int lds_ld_b32(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_ld_b32_x2(unsigned a0, unsigned a1, int& v0, int& v1) {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_ld_b32_x6(const unsigned (&a)[6], int (&v)[6]) {
+    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %7\n\tds_read_b32 %2, %8\n\tds_read_b32 %3, %9\n\tds_read_b32 %4, %10\n\t"
+                 "ds_read_b32 %5, %11\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]) : "memory");
+}
+__device__ __forceinline__ void lds_ld_b64_x2(unsigned a0, unsigned a1, f32x2& v0, f32x2& v1) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_st_b32(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st_b64(unsigned addr, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st_b128(unsigned addr, f32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+#define BX_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// The lane id again, through an asm the optimiser cannot see through: what a stage derives from it (row numbers, swizzles,
+// LDS addresses — dozens of values) is then recomputed per stage instead of being hoisted out of the chunk loop into
+// registers that the block sums need.
+__device__ __forceinline__ int opaque_lane(int lane) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return lane + z;
+}
+
+#ifndef GHF_BX_U
+#define GHF_BX_U 6           // units per helper lane
+#endif
+#ifndef GHF_BX_UW
+#define GHF_BX_UW 32         // sum positions per unit
+#endif
+#ifndef GHF_BX_SB
+#define GHF_BX_SB 2          // fold: 16-byte reads per step
+#endif
+#ifndef GHF_BX_RD
+#define GHF_BX_RD 3          // fold: steps in flight (<= 4)
+#endif
+#ifndef GHF_BX_CR
+#define GHF_BX_CR 76         // rows per chunk
+#endif
+
+template <int D> struct BxCfg;
+template <> struct BxCfg<128> {
+    static constexpr int U = GHF_BX_U, UW = GHF_BX_UW, CR = GHF_BX_CR;
+    static constexpr int BN = 2 * U * UW;          // 4 helper waves x 64 lanes x U units x UW positions / 128
+    static constexpr int MTC = (CR + 15) / 16;     // row tiles per chunk
+};
+
+struct BxChunk { int r; int e0; int rows; };
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void message_bx_kernel(
+    const float* __restrict__ h, const void* __restrict__ h_split, int64_t N, const uint32_t* __restrict__ sorted_key,
+    const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
+    const int32_t* __restrict__ item_tab, int64_t item0, float* __restrict__ partial,
+    const int32_t* __restrict__ indeg, int R,
+    const void* __restrict__ Wsplit, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail) {
+    using C = BxCfg<D>;
+    constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, U = C::U, UW = C::UW;
+    constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
+    constexpr int KS = D / 32;                // k-steps of 32 per phase
+    constexpr int NKS = 2 * KS;
+    constexpr int NT = D / 16;                // 16-column fragments of the output
+    constexpr int NTW = NT / TW;              // fragments per consumer wave (2)
+    constexpr int NPL = 2;                    // pieces (hi, lo)
+    constexpr int ROWB = D * 2;               // bytes per row of one fp16 plane of an A tile
+    constexpr int PLANE = CR * ROWB;          // bytes per plane (a multiple of 1 KiB: CR % 4 == 0)
+    constexpr int TILE = NPL * PLANE;         // one A tile; also the size of the staging tile Y [CR][D] fp32
+    constexpr int HROW = NPL * D * 2;         // bytes per node of h_split
+    constexpr int CRP = 16 * MTC;             // rows an A tile is read as (the last tile's dead rows are never used)
+    constexpr int MSTR = 4 * CRP + 4;         // words per chunk descriptor: sc_u, sc_v, src id, dst id [CRP each], rows
+    constexpr int NU = D / UW;                // units per node
+    constexpr int NPW = BN / TW;              // nodes per helper wave
+    constexpr int RBN = CR / 4;               // 4-row blocks (= 1 KiB DMA pieces) per plane
+    constexpr int RBW = (RBN + TW - 1) / TW;  // pieces per helper wave and plane
+    constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
+    static_assert(NTW == 2 && CR % 4 == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
+    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 3 * TILE, TAB_OFF = 4 * TILE, META_OFF = TAB_OFF + BN * 4,
+                       DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024;      // ZERO: 128 bytes of zeros
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;       // LDS byte address of smem (0 unless static LDS exists)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool helper = w >= TW;
+    const int tw = w & 3;                      // consumer: column group; helper: hw
+    const int q = lane >> 4, c16 = lane & 15;
+    const i32x4 item = *(const i32x4*)(item_tab + 4 * (size_t)(item0 + blockIdx.x));
+    const int64_t blk = __builtin_amdgcn_readfirstlane(item[0]);
+    const int slot = __builtin_amdgcn_readfirstlane(item[3]);
+    const int64_t node0 = blk * BN;
+    const int nrows = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
+    const uint32_t seg0 = (uint32_t)(blk * R);
+    const int c_begin = __builtin_amdgcn_readfirstlane(item[1]);
+    const int c_end = __builtin_amdgcn_readfirstlane(item[2]);
+    const int nchunks = c_end - c_begin;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));    // opaque 0: keeps the descriptor loads on the vector path
+
+    auto load_desc = [&](int k) -> i32x2 {                              // past the end: the item's first chunk (ignored)
+        const int c = c_begin + (k < nchunks ? k : 0) + vzero;
+        return *bx_at<i32x2>(chunk_tab, (uint32_t)c * 8u);
+    };
+    auto decode = [&](i32x2 d) -> BxChunk {
+        const int w0 = __builtin_amdgcn_readfirstlane(d[0]), w1 = __builtin_amdgcn_readfirstlane(d[1]);
+        return BxChunk{w1 >> 8, w0, w1 & 127};
+    };
+    auto meta_off = [&](int j) -> unsigned { return META_OFF + (unsigned)(j & 3) * (MSTR * 4); };
+    const uint32_t hsc_off = (uint32_t)((uint64_t)N * HROW);            // the row scales follow the N split rows
+
+    // ---- fused tail from LDS (both roles; the helpers dump their registers first, NPW / 2 nodes per wave at a time) ----
+    // dump row v = (NPW/2) * hw + i  <->  node NPW * hw + (NPW/2) * half + i   (helper lanes 32*half .. 32*half + 31)
+    constexpr int HN = BN / 2, HPW = NPW / 2;
+    auto tail_half = [&](int half, auto rb_c) {          // rb_c: rows in flight per wave (fewer while the helpers still hold sums)
+        const float* acc_lds = (const float*)smem;
+        constexpr int CPL = D / 64;
+        int col[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) col[c] = 32 * (lane >> 4) + 16 * c + (lane & 15);
+        auto node_of = [&](int v) -> int { return (v / HPW) * NPW + half * HPW + (v % HPW); };   // block-local node of dump row v
+        if (slot >= 0) {                               // one item of a split block: raw sums (column order) to my slot
+            float* __restrict__ ps = partial + (size_t)slot * BN * D;
+            for (int v = w; v < HN; v += NWV)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) ps[(size_t)node_of(v) * D + col[c]] = acc_lds[v * D + lane * CPL + c];
+            return;
+        }
+        float gm[CPL], bt[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            gm[c] = no_tail ? 1.f : gamma[col[c]];
+            bt[c] = no_tail ? 0.f : beta[col[c]];
+        }
+        constexpr int RB = decltype(rb_c)::value;
+        for (int v0 = w; v0 < HN; v0 += NWV * RB) {
+            float x[RB][CPL], inv[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int v = v0 + rb * NWV;
+                const int nl = node_of(v < HN ? v : HN - 1);
+                const int64_t node = node0 + (nl < nrows ? nl : nrows - 1);
+                const int deg = indeg[node];
+                inv[rb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + col[c]];
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int v = v0 + rb * NWV;
+                const int vc = v < HN ? v : HN - 1;
+                const int nl = node_of(vc);
+                const bool live = v < HN && nl < nrows;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const float a = acc_lds[vc * D + lane * CPL + c] * inv[rb];
+                    x[rb][c] = no_tail ? a : fmaxf(a + x[rb][c], 0.f);
+                    s += x[rb][c];
+                }
+                if (!no_tail) {
+                    const float mean = wave_sum(s) * (1.0f / D);
+                    float var = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) { const float t = x[rb][c] - mean; var += t * t; }
+                    const float rstd = 1.0f / sqrtf(wave_sum(var) * (1.0f / D) + eps);
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) x[rb][c] = (x[rb][c] - mean) * rstd * gm[c] + bt[c];
+                }
+                float up = 1.f;
+                if (h_split_out) {                       // the same row cut into fp16 pieces, for the next layer's gathers
+                    float mx = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) mx = fmaxf(mx, fabsf(x[rb][c]));
+                    const int sh = split2h_shift(wave_absmax(mx));
+                    up = pow2f(sh);
+                    if (lane == 0 && live) *(float*)((char*)h_split_out + (size_t)hsc_off + (size_t)(node0 + nl) * 4) = pow2f(-sh);
+                }
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + nl) * D + col[c]] = x[rb][c];
+                    if (h_split_out) {
+                        _Float16* __restrict__ sp = (_Float16*)h_split_out + (size_t)(node0 + nl) * (NPL * D);
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) {
+                            _Float16 hi, lo;
+                            split2h(x[rb][c] * up, hi, lo);
+                            sp[col[c]] = hi;
+                            sp[D + col[c]] = lo;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    if (helper) {
+        float sums[U][UW];                                              // the block sums (see header)
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+#pragma unroll
+            for (int i = 0; i < UW; ++i) sums[k][i] = 0.f;
+        // ================================================ HELPERS ================================================
+        const int hw = tw;
+        const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)h_split, 0, (int)hsc_off, 0x00020000);
+        // ---- a chunk's descriptor: lane l < RPH handles row RPH*hw + l ---------------------------------------------
+        struct Words { int src; int key; };
+        struct Scales { float u; float v; };
+        auto load_words = [&](const BxChunk& c, int ln) -> Words {
+            const int mrow = hw * RPH + (ln < RPH ? ln : RPH - 1);
+            const int rc = mrow < c.rows ? mrow : c.rows - 1;               // rows >= 1; pad rows repeat the last row
+            const uint32_t eo = (uint32_t)(c.e0 + rc) * 4u;
+            return Words{*bx_at<int>(sorted_src, eo), *bx_at<int>(sorted_key, eo)};
+        };
+        auto dst_of = [&](const BxChunk& c, const Words& wd) -> uint32_t {
+            const uint32_t kbase = (seg0 + (uint32_t)c.r) * (uint32_t)BN;
+            return (uint32_t)node0 + ((uint32_t)wd.key - kbase);
+        };
+        auto load_scales = [&](const BxChunk& c, const Words& wd) -> Scales {
+            const uint32_t nu = (uint32_t)(wd.src & SRC_MASK), nv = dst_of(c, wd);
+            return Scales{*bx_at<float>(h_split, hsc_off + nu * 4u), *bx_at<float>(h_split, hsc_off + nv * 4u)};
+        };
+        auto publish = [&](int j, const BxChunk& c, const Words& wd, const Scales& sc, int ln) {
+            const unsigned m = lds0 + meta_off(j);
+            const int mrow = hw * RPH + (ln < RPH ? ln : RPH - 1);
+            if (ln < RPH && mrow < CRP) {
+                lds_st_b32(m + 4 * mrow, __float_as_int(sc.u));
+                lds_st_b32(m + 4 * (CRP + mrow), __float_as_int(sc.v));
+                lds_st_b32(m + 4 * (2 * CRP + mrow), wd.src & SRC_MASK);
+                lds_st_b32(m + 4 * (3 * CRP + mrow), (int)dst_of(c, wd));
+            }
+            if (hw == 0 && ln == 0) lds_st_b32(m + 4 * (4 * CRP), c.rows);
+        };
+        // ---- LDS-DMA gather of one A tile: piece = rows 4*rb .. 4*rb+3 of one plane (1 KiB), 16 lanes per row; the
+        // granules of a row are XOR-swizzled by (row & 15) as the consumers' fragment reads expect (message_hx.hip) ----
+        auto dma_tile = [&](unsigned tile_off, int j, int which /*2: src ids, 3: dst ids*/, int rows, bool nt, int lane) {
+            const unsigned ids = lds0 + meta_off(j) + 4 * (which * CRP);
+            static_assert(RBW <= 6, "ids of a tile: one batched read");
+            unsigned ia[6];
+            int id[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ia[i] = ids + 4 * (4 * (hw + TW * (i < RBW ? i : 0)) + (lane >> 4));
+            lds_ld_b32_x6(ia, id);
+#pragma unroll
+            for (int i = 0; i < RBW; ++i) {
+                const int rb = hw + TW * i, row = 4 * rb + (lane >> 4);
+                const int g = (lane & 15) ^ (row & 15);
+                // dead rows: an offset past the end of the buffer (zeros, no memory access)
+                const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : 0x7FFFFF00;
+                // a piece past the tile (RBN not a multiple of 4 waves) lands in a scratch KiB
+                const unsigned dst = rb < RBN ? tile_off + (unsigned)rb * 1024u : DUMMY_OFF;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const unsigned d = __builtin_amdgcn_readfirstlane(dst + (rb < RBN ? pl * PLANE : 0));
+                    if (nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lptr_t)(smem + d), 16, voff + pl * ROWB, 0, 0, 2);
+                    else    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lptr_t)(smem + d), 16, voff + pl * ROWB, 0, 0, 0);
+                }
+            }
+        };
+        // ---- table: node -> the last row of its run in chunk j (rows sorted by destination) -----------------------
+        auto table_write = [&](int j, int rows, int lane) {
+            const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
+            const int row = hw * RPH + lane;
+            const int rr = row < rows ? row : rows - 1;
+            int d0, d1;
+            lds_ld_b32_x2(dd + 4 * rr, dd + 4 * (rr + 1 < rows ? rr + 1 : rr), d0, d1);
+            if (lane < RPH && row < rows && (row + 1 >= rows || d0 != d1)) lds_st_b32(lds0 + TAB_OFF + 4 * (unsigned)(d0 - (int)node0), row);
+        };
+        auto table_clear = [&](int lane) {
+#pragma unroll
+            for (int i = 0; i < (NPW + 63) / 64; ++i)
+                if (lane + 64 * i < NPW) lds_st_b32(lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + lane + 64 * i), -1);
+        };
+        // ---- fold chunk j's staged rows into the registers -------------------------------------------------------
+        // Y [row][position], the two 32-position halves of a 64-position group swapped when (row >> 2) & 1 (the consumers'
+        // ds_write_b64 of four row groups then touch every bank exactly twice)
+        auto fold = [&](int j, int rows, int lane) {
+            const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
+            const unsigned Y = lds0 + Y_OFF;
+            // 1. runs of equal destinations owned by this wave: add row r into row r + 1, ascending
+#pragma unroll
+            for (int pass = 0; pass < (CR + 63) / 64; ++pass) {
+                const int r = pass * 64 + lane;
+                const int rr = r + 1 < rows ? r : 0;
+                int a, b;
+                lds_ld_b32_x2(dd + 4 * rr, dd + 4 * (rr + 1), a, b);
+                const int nl = a - (int)node0 - hw * NPW;
+                unsigned long long mask = __ballot(r + 1 < rows && a == b && nl >= 0 && nl < NPW);
+                while (mask) {
+                    const int r0 = pass * 64 + (int)__builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const unsigned pa = Y + (unsigned)r0 * (D * 4) + (unsigned)(((2 * lane) ^ (((r0 >> 2) & 1) << 5)) * 4);
+                    const unsigned pb = Y + (unsigned)(r0 + 1) * (D * 4) + (unsigned)(((2 * lane) ^ ((((r0 + 1) >> 2) & 1) << 5)) * 4);
+                    f32x2 x, y;
+                    lds_ld_b64_x2(pa, pb, x, y);
+                    lds_st_b64(pb, x + y);
+                }
+            }
+            // 2. every owner lane: the staged row of its node, if any
+            static_assert(U <= 12, "table reads: two batches of six");
+            int ri[12];
+#pragma unroll
+            for (int k0 = 0; k0 < U; k0 += 6) {
+                unsigned ta[6];
+                int tv[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ta[k] = lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + (U * lane + (k0 + k < U ? k0 + k : 0)) / NU);
+                lds_ld_b32_x6(ta, tv);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ri[k0 + k] = tv[k];
+            }
+            // the unit's bytes in Y (a lane whose node has no row in this chunk reads — and adds — zeros: no branch)
+            unsigned ua[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int part = (U * lane + k) % NU, r = ri[k];
+                ua[k] = r >= 0 ? Y + (unsigned)r * (D * 4) + (unsigned)(((part * UW) ^ (((r >> 2) & 1) << 5)) * 4) : lds0 + ZERO_OFF;
+            }
+            // all 16-byte reads of the lane as one sequence, SB per step, RD steps in flight
+            constexpr int SB = GHF_BX_SB, RD = GHF_BX_RD, RPU = UW / 4, NRD = U * RPU, NST = NRD / SB;
+            static_assert(NRD % SB == 0, "reads per lane must be a multiple of the step");
+            f32x4 y[RD][SB];
+            auto issue = [&](int st, f32x4 (&dstv)[SB]) {
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int g = st * SB + i;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dstv[i]) : "v"(ua[g / RPU]), "n"(16 * (g % RPU)) : "memory");
+                }
+            };
+#pragma unroll
+            for (int st = 0; st < RD - 1 && st < NST; ++st) issue(st, y[st % RD]);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + RD - 1 < NST) issue(st + RD - 1, y[(st + RD - 1) % RD]);
+                static_assert(SB == 2, "the counted wait below names two destinations");
+                const int left = (NST - 1 - st) < (RD - 1) ? (NST - 1 - st) : (RD - 1);      // steps still in flight behind this one
+                // the wait names this step's destinations: nothing may read them above it
+                if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1])::"memory");
+                else if (left == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(SB) : "memory");
+                else if (left == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(2 * SB) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(3 * SB) : "memory");
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int g = st * SB + i, k = g / RPU, o = 4 * (g % RPU);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sums[k][o + e] += y[st % RD][i][e];
+                    // pin the sums behind this step: otherwise all reads are issued first (192 live registers) and the adds follow
+                    asm volatile("" : "+v"(sums[k][o]), "+v"(sums[k][o + 1]), "+v"(sums[k][o + 2]), "+v"(sums[k][o + 3]));
+                }
+            }
+        };
+
+        // ---- prologue: descriptors of chunks 0..2 published, source rows of chunks 0 and 1 in their tiles ------------
+        // Pipeline of a chunk j's descriptor: chunk_tab entry requested in stage (j-6,1), its words (source id, key) in
+        // (j-5,0), its rows' scales in (j-4,0), published in (j-3,1); the values move up one place per chunk AFTER they have
+        // arrived (a register copy of a value still in flight would wait for it, and for the DMA issued before it).
+        BxChunk ch[6];                                     // ch[i] = chunk k + i
+        Words wd3{0, 0}, wd4{0, 0}, wd5{0, 0};             // words of chunks k + 3, k + 4, k + 5
+        Scales sc3{1.f, 1.f}, sc4{1.f, 1.f};               // scales of chunks k + 3, k + 4
+        table_clear(lane);
+        if (hw == 0 && lane < 32) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);
+        int prev_rows = 1;
+        if (nchunks > 0) {
+            i32x2 dd[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dd[j] = load_desc(j);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) ch[j] = decode(dd[j]);
+            Words wd[5];
+            Scales sc[4];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) wd[j] = load_words(ch[j], lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[j] = load_scales(ch[j], wd[j]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) publish(j, ch[j], wd[j], sc[j], lane);
+            wd3 = wd[3];
+            sc3 = sc[3];
+            wd4 = wd[4];
+        }
+        BX_LGKM0();
+        __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0..2 visible to all helper waves
+        // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
+        if (nchunks > 0) {
+            dma_tile(P0_OFF, 0, 2, ch[0].rows, true, lane);
+            dma_tile(P0_OFF + TILE, 1, 2, ch[1].rows, true, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        i32x2 d6{0, 0};
+        for (int k = 0; k < nchunks; ++k) {
+            __builtin_amdgcn_s_barrier();                  // ---- stage (k,0)
+            const int l0 = opaque_lane(lane);
+            dma_tile(P1_OFF, k, 3, ch[0].rows, false, l0);
+            if (k > 0) {
+                fold(k - 1, prev_rows, l0);
+                table_clear(l0);
+            }
+            // (behind the fold: the wait for d6 is also a wait for the source-row DMA issued before it)
+            if (k > 0) ch[5] = decode(d6);
+            sc4 = load_scales(ch[4], wd4);
+            wd5 = load_words(ch[5], l0);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the P1 pieces (and everything older) have landed
+            BX_LGKM0();
+            __builtin_amdgcn_s_barrier();                  // ---- stage (k,1)
+            const int l1 = opaque_lane(lane);
+            dma_tile(P0_OFF + (k & 1) * TILE, k + 2, 2, ch[2].rows, true, l1);
+            table_write(k, ch[0].rows, l1);
+            d6 = load_desc(k + 6);
+            publish(k + 3, ch[3], wd3, sc3, l1);
+            wd3 = wd4;
+            sc3 = sc4;
+            wd4 = wd5;
+            prev_rows = ch[0].rows;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ch[j] = ch[j + 1];
+            BX_LGKM0();
+        }
+        __builtin_amdgcn_s_barrier();                      // ---- epilogue stage: the last chunk's rows
+        if (nchunks > 0) fold(nchunks - 1, prev_rows, opaque_lane(lane));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
+        BX_LGKM0();
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if ((lane >> 5) == half) {
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int u = U * lane + k, nl = u / NU, part = u % NU;
+                    const unsigned a = lds0 + (unsigned)(hw * HPW + (nl - half * HPW)) * (D * 4) + (unsigned)part * (UW * 4);
+#pragma unroll
+                    for (int i = 0; i < UW / 4; ++i)
+                        lds_st_b128(a + 16 * i, (f32x4){sums[k][4 * i], sums[k][4 * i + 1], sums[k][4 * i + 2], sums[k][4 * i + 3]});
+                }
+            }
+            BX_LGKM0();
+            __syncthreads();
+            if (half == 0) tail_half(0, std::integral_constant<int, 4>{});
+            else tail_half(1, std::integral_constant<int, 12>{});
+        }
+    } else {
+        // =============================================== CONSUMERS ===============================================
+        // B fragments (GHF_WLAYOUT_SPLIT2H): Wh[r][o/16][kk/32][piece][lane][8] fp16, then one float 2^-s per relation
+        const uint32_t wsc_off = (uint32_t)((uint64_t)R * 2 * D * D * (NPL * 2));
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wsplit, 0, (int)wsc_off, 0x00020000);
+        auto b_soff = [&](int r, int ph, int t) -> int {
+            return __builtin_amdgcn_readfirstlane((((r * NT + tw * NTW + t) * NKS + ph * KS) * NPL) * 1024);
+        };
+        const int lane16 = lane * 16;
+        i32x4 b[KS][NTW][NPL];
+        auto load_b_step = [&](int r, int ph, int j) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    b[j][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * (NPL * 1024), 0);
+        };
+        f32x4 acc[MTC][NTW];
+        const int arow = c16 * ROWB;
+        auto compute_stage = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+                                 const float (&bias_v)[NTW]) {
+            f32x4 part[MTC][NTW];
+#pragma unroll
+            for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) part[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 sc[MTC];
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) sc[m] = *(const f32x4*)(meta + ph * CRP + m * 16 + 4 * q);
+            i32x4 a[3][NPL];
+            auto lda = [&](int j, int m, i32x4 (&dst)[NPL]) {
+                const char* src = Abuf + arow + (((4 * j + q) ^ c16) << 4) + m * 16 * ROWB;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) dst[pl] = *(const i32x4*)(src + pl * PLANE);
+            };
+            lda(0, 0, a[0]);
+            lda(0, 1, a[1]);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+#pragma unroll
+                for (int m = 0; m < MTC; ++m) {
+                    const int p = j * MTC + m, cur = p % 3;
+                    if (p + 2 < KS * MTC) lda((p + 2) / MTC, (p + 2) % MTC, a[(p + 2) % 3]);
+                    if (m < mt) {
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) {
+                            auto fma = [&](int pa, int pb) {
+                                part[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[cur][pa]),
+                                                                                    __builtin_bit_cast(f16x8, b[j][t][pb]),
+                                                                                    part[m][t], 0, 0, 0);
+                            };
+                            fma(1, 0); fma(0, 1);                               // lo*hi, hi*lo
+                            fma(0, 0);                                          // hi*hi
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_b_step(r_next, ph_next, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                if (m >= mt) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float f = sc[m][s] * wscale;
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[m][t][s] = fmaf(part[m][t][s], f, ph == 0 ? bias_v[t] : acc[m][t][s]);
+                }
+            }
+        };
+        // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1)
+        const unsigned ybase = lds0 + Y_OFF + (unsigned)(4 * q) * (D * 4) + (unsigned)(((32 * tw + 2 * c16) ^ ((q & 1) << 5)) * 4);
+        auto write_rows = [&](int mt) {
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                if (m >= mt) continue;
+                // the last tile's rows past CR do not exist in Y (the table follows it)
+                if (16 * m + 16 > CR && 16 * m + 4 * q >= CR) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ybase), "v"((f32x2){acc[m][0][s], acc[m][1][s]}),
+                                 "n"((16 * m + s) * (D * 4)) : "memory");
+            }
+        };
+
+        BxChunk ch{0, 0, 1};
+        i32x2 dn{0, 0};
+        float bias_v[NTW] = {}, bias_n[NTW] = {}, wscale = 1.f, wscale_n = 1.f;
+        auto load_rel_words = [&](int r, float& ws, float (&bv)[NTW]) {
+            ws = *bx_at<float>(Wsplit, wsc_off + (uint32_t)(r + vzero) * 4u);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bv[t] = *bx_at<float>(bias, (uint32_t)(r * D + (tw * NTW + t) * 16 + c16) * 4u);
+        };
+        if (nchunks > 0) {
+            ch = decode(load_desc(0));
+            dn = load_desc(1);
+            load_rel_words(ch.r, wscale, bias_v);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) load_b_step(ch.r, 0, j);
+        }
+        __syncthreads();                                   // barrier A
+        for (int k = 0; k < nchunks; ++k) {
+            const int mt = (ch.rows + 15) >> 4;
+            const int* meta = (const int*)(smem + meta_off(k));
+            __syncthreads();                               // stage (k,0): phase 0
+            const BxChunk nx = decode(dn);
+            compute_stage(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, ch.r, 1, bias_v);
+            __syncthreads();                               // stage (k,1): phase 1, then the chunk's rows are staged
+            dn = load_desc(k + 2);
+            load_rel_words(nx.r, wscale_n, bias_n);
+            compute_stage(mt, 1, smem + P1_OFF, meta, wscale, nx.r, 0, bias_v);
+            write_rows(mt);
+            ch = nx;
+            wscale = wscale_n;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bias_v[t] = bias_n[t];
+            BX_LGKM0();
+        }
+        __syncthreads();                                   // epilogue stage
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            __syncthreads();
+            tail_half(half, std::integral_constant<int, 12>{});
+        }
+    }
+
+}
+
+template <int D>
+static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
+    using C = BxCfg<D>;
+    constexpr int CRP = 16 * C::MTC;
+    constexpr size_t lds = (size_t)4 * 2 * C::CR * (D * 2) + (size_t)C::BN * 4 + 4 * (4 * CRP + 4) * 4 + 1024 + 128;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert((size_t)(C::BN / 2) * D * 4 <= (size_t)3 * 2 * C::CR * (D * 2), "the tail's dump of half a block must fit the three A tiles");
+    GHF_REQUIRE(a.block_nodes == C::BN, "message(bx): plan block_nodes=%d, kernel for d=%d needs %d", a.block_nodes, D, C::BN);
+    GHF_REQUIRE(a.wlayout == GHF_WLAYOUT_SPLIT2H, "message(bx): weights must be in SPLIT2H layout");
+    GHF_REQUIRE(a.chunk_tab && a.item_tab && a.blk_item_off, "message(bx): the plan's chunk / item tables are missing");
+    GHF_REQUIRE(a.h_split, "message(bx): h_split is missing (ghf_split_rows)");
+    const int64_t row_end = a.row0 + a.rows;
+    GHF_REQUIRE(row_end == a.N || row_end % C::BN == 0, "message(bx): row range must end on a block boundary or at N");
+    if (a.rows <= 0) return GHF_OK;
+    GHF_REQUIRE((uint64_t)a.N * (D * 4 + 4) < (1ull << 31) && (uint64_t)a.E * 4 < (1ull << 32) &&
+                    (uint64_t)a.R * (2 * D * D * 4 + 4) < (1ull << 32),
+                "message(bx): 32-bit byte offsets need N*(4d+4) below 2 GiB, E*4 and R*(8d*d+4) below 4 GiB");
+    GHF_SET_MAX_LDS(message_bx_kernel<D>, lds);
+    GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(bx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
+    GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(bx): split blocks need the `partial` scratch");
+    message_bx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
+                                                                   a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
+                                                                   a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
+                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
+    GHF_LAUNCH_CHECK();
+    if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
+    return GHF_OK;
+}
+
+bool message_bx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks) {
+    if (d != 128) return false;
+    *block_nodes = BxCfg<128>::BN;
+    *chunk_rows = BxCfg<128>::CR;
+    *split_chunks = 128;
+    return true;
+}
+
+bool message_bx_owns(int d, int block_nodes) { return d == 128 && block_nodes == BxCfg<128>::BN; }
+
+int launch_message_bx(const MsgArgs& a, hipStream_t stream) {
+    if (a.d == 128) return launch_bx_for<128>(a, stream);
+    return set_err(GHF_EUNSUPPORTED, "message(bx): no kernel for d=%d", a.d);
+}
+
+}  // namespace ghf

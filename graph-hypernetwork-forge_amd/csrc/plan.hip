@@ -197,7 +197,8 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
                 (unsigned long long)key_space);
     if (BN > 1) {
         GHF_REQUIRE(N <= (1ll << SRC_BITS), "plan: block plans pack the run head above bit %d of the source id", SRC_BITS);
-        GHF_REQUIRE(CR > 0 && CR < 128 && (CR % 16) == 0 && R < (1 << 23), "plan: chunk_rows must be a multiple of 16 below 128, R < 2^23");
+        // (kernels that use the run heads / the `cross` bit need chunks that start on a 16-row tile of their group: CR % 16 == 0)
+        GHF_REQUIRE(CR > 0 && CR < 128 && (CR % 4) == 0 && R < (1 << 23), "plan: chunk_rows must be a multiple of 4 below 128, R < 2^23");
         GHF_REQUIRE(T > 0 && item_tab && blk_item_off, "plan: block plans need split_chunks > 0, item_tab and blk_item_off");
     }
     GHF_REQUIRE(ws_bytes >= plan_workspace_bytes(N, E, R, BN, CR), "plan: workspace too small");

@@ -80,7 +80,7 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
  *   status [3] int32: [0] 0 ok, bit0 = a src/dst outside [0,N), bit1 = a rel outside [0,R) (read it back
  *              before trusting the plan; offending edges are dropped); [1] number of items; [2] number of
  *              scratch slots (each BN*d floats) ghf_message_layer_fwd needs in `partial`.
- * Requires ceil(N/BN)*BN*R < 2^32, E < 2^31, R < 2^23, chunk_rows % 16 == 0, chunk_rows < 128, split_chunks > 0. */
+ * Requires ceil(N/BN)*BN*R < 2^32, E < 2^31, R < 2^23, chunk_rows % 4 == 0 (% 16 for the kernels that read the run heads), chunk_rows < 128, split_chunks > 0. */
 size_t  ghf_plan_workspace_bytes(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
 int64_t ghf_plan_max_chunks(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows);
 int64_t ghf_plan_max_items(int64_t N, int64_t E, int R, int block_nodes, int chunk_rows, int split_chunks);

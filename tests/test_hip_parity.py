@@ -272,7 +272,7 @@ def test_split_rows_and_the_fused_tail_agree(kernel):
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
     wl = plan.wlayout
-    assert wl == {"hx": _native.WLAYOUT_SPLIT2H, "sx": _native.WLAYOUT_SPLIT3}[kernel]
+    assert wl == {"hx": _native.WLAYOUT_SPLIT2H, "bx": _native.WLAYOUT_SPLIT2H, "sx": _native.WLAYOUT_SPLIT3}[kernel]
     h_d = t(h)
     hs = _native.split_rows(h_d, wl)
     want = np.stack(_split3_np(h), axis=1).view(np.int16) if kernel == "sx" else _rows_split2h(h)
@@ -300,7 +300,7 @@ def _pack_weights(plan, Wm, Ws):
     return t(Wm), t(Ws)
 
 
-@pytest.fixture(params=["hx", "sx", "pp"])
+@pytest.fixture(params=["hx", "bx", "sx", "pp"])
 def kernel(request, monkeypatch):
     """The contractions of the d = 128 message kernel: two fp16 pieces (default), three bf16 pieces, and
     v_mfma_f32_16x16x4_f32."""
