@@ -59,7 +59,8 @@ def layer_flops(N, E, R, d):
 
 def kern_name(plan, d):
     from graph_hypernetwork_forge_amd import _native
-    return {_native.WLAYOUT_SPLIT2H: "message_hx_kernel", _native.WLAYOUT_SPLIT3: "message_sx_kernel"}.get(
+    return {_native.WLAYOUT_SPLIT2H: "message_bx_kernel" if plan.block_nodes == 384 else "message_hx_kernel",
+            _native.WLAYOUT_SPLIT3: "message_sx_kernel"}.get(
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
@@ -226,7 +227,7 @@ def main():
         if pmc:
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
             traffic_src = "profiles/r01_message_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2)"
-        kern = {_native.WLAYOUT_SPLIT2H: "message_hx_kernel<128>", _native.WLAYOUT_SPLIT3: "message_sx_kernel<128>"}.get(
+        kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<128>", _native.WLAYOUT_SPLIT3: "message_sx_kernel<128>"}.get(
             plan.wlayout, "message_pp_kernel<%d>" % d if plan.block_nodes > 1 else "message_generic_kernel")
         if wide:
             kern = "edge_transform_kernel + segment_tail_kernel<%d> (one layer)" % (d // 64)

@@ -32,7 +32,14 @@ if _b:
 _t = _re.search(r"opt(\d+)", VARIANT)
 if _t:
     FLAGS.append("-DGHF_OPT=" + _t.group(1))          # A/B switches of message_hx.hip (see GHF_OPT there)
-_m = _re.search(r"exp(\d+)", VARIANT)
+_x = _re.search(r"bxexp(\d+)", VARIANT)
+if _x:
+    FLAGS.append("-DGHF_BXEXP=" + _x.group(1))         # compile-time ablations of message_bx.hip (timing only)
+for _k in ("U", "UW", "CR", "SB", "RD", "AD", "PK"):               # message_bx.hip geometry: e.g. GHF_VARIANT=bxU5_bxCR64
+    _g = _re.search(r"bx%s(\d+)" % _k, VARIANT)
+    if _g:
+        FLAGS.append("-DGHF_BX_%s=%s" % (_k, _g.group(1)))
+_m = _re.search(r"(?<!bx)exp(\d+)", VARIANT)
 if _m:
     # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags
     # of the "ablate" build they add no branches, so what is left runs exactly as in the product ("stampsexp<mask>"

@@ -325,7 +325,7 @@ def prefer_rs(d: int, R: int) -> bool:
     always where no destination-block kernel exists (d >= 256); at d = 128 from about 128 relations on — the block
     kernel re-streams a relation's weights per (block, relation) chunk, so its time grows with R (C3-sized graph: 4.1 ms per
     layer at R = 64, 11.3 ms at 256) while the relation-stationary layer's does not (6.0 ms)."""
-    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("hx", "sx", "pp", "lockstep"):
+    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("bx", "hx", "sx", "pp", "lockstep"):
         return False
     return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
 

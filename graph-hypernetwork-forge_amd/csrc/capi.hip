@@ -32,9 +32,10 @@ const char* ghf_last_error(void) { return err_buf(); }
 int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks) {
     if (!block_nodes || !wlayout || !chunk_rows || !split_chunks) return set_err(GHF_EINVAL, "message_config: null output pointer");
     int bn = 1, cr = 0, sc = 0;
-    // GHF_KERNEL selects the contraction for A/B runs: "hx" (default) = two fp16 pieces, three products
-    // (message_hx.hip), "sx" = three bf16 pieces, six products (message_sx.hip), "pp" / "lockstep" =
-    // v_mfma_f32_16x16x4_f32 (message_pp.hip / message_mfma.hip)
+    // GHF_KERNEL selects the d = 128 kernel for A/B runs: "bx" (default) = two fp16 pieces, three products, block sums in
+    // registers (message_bx.hip); "hx" = the same contraction with the block sums in LDS (message_hx.hip); "sx" = three
+    // bf16 pieces, six products (message_sx.hip); "pp" / "lockstep" = v_mfma_f32_16x16x4_f32 (message_pp.hip /
+    // message_mfma.hip)
     // "rs" / "rs32" / "generic": a CSR plan also where a destination-block kernel exists (A/B of the relation-stationary
     // layer at d = 128)
     const char* kv = getenv("GHF_KERNEL");
@@ -43,7 +44,7 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
         *wlayout = GHF_WLAYOUT_NATURAL;
         *chunk_rows = 0;
         *split_chunks = 0;
-    } else if (kv && !strcmp(kv, "bx") && message_bx_config(d, &bn, &cr, &sc)) {
+    } else if ((!kv || !strcmp(kv, "bx")) && message_bx_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_SPLIT2H;
         *chunk_rows = cr;

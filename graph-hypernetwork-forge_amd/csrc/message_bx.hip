@@ -93,8 +93,45 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_RD
 #define GHF_BX_RD 3          // fold: steps in flight (<= 4)
 #endif
+// Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results): 1 no B refills, 2 no A-tile DMA, 4 no MFMAs,
+// 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table)
+#ifndef GHF_BXEXP
+#define GHF_BXEXP 0
+#endif
+#ifndef GHF_BX_AD
+#define GHF_BX_AD 2          // consumers: A-fragment positions read ahead (2, 4, 6 measured the same)
+#endif
+#ifndef GHF_BX_PK
+#define GHF_BX_PK 1          // fold: v_pk_add_f32 (two per 16 bytes) instead of four v_add_f32: 3.56 -> 3.52 ms at C3
+#endif
 #ifndef GHF_BX_CR
 #define GHF_BX_CR 76         // rows per chunk
+#endif
+
+// Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals per segment.
+// consumers: 0 barrier wait, 1 phase-0 stage, 2 phase-1 stage, 3 staging writes
+// helpers:   0 barrier wait, 1 DMA issue, 2 fold + table clear, 3 wait for the P1 pieces, 4 descriptor work, 6 epilogue + tail
+#ifdef GHF_STAMPS
+__device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
+#define BX_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0
+#define BX_STAMP(i)                                                                            \
+    do {                                                                                       \
+        unsigned long long _t;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((i) >= 0) st_acc[(i) < 0 ? 0 : (i)] += _t - st_last;                               \
+        st_last = _t;                                                                          \
+    } while (0)
+#define BX_STAMP_FLUSH()                                                                       \
+    do {                                                                                       \
+        if (lane == 0 && blockIdx.x < 8192)                                                    \
+            for (int i = 0; i < 8; ++i) ghf_bx_stamp_buf[((size_t)blockIdx.x * 8 + w) * 8 + i] = st_acc[i]; \
+    } while (0)
+#else
+#define BX_STAMP_DECL
+#define BX_STAMP(i)
+#define BX_STAMP_FLUSH()
 #endif
 
 template <int D> struct BxCfg;
@@ -136,7 +173,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
     static_assert(NTW == 2 && CR % 4 == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
     constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 3 * TILE, TAB_OFF = 4 * TILE, META_OFF = TAB_OFF + BN * 4,
-                       DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024;      // ZERO: 128 bytes of zeros
+                       DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: 128 bytes of zeros
+                       FLAG_OFF = ZERO_OFF + 128;         // FLAG: per helper wave, the number of chunks whose rows it has folded
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;       // LDS byte address of smem (0 unless static LDS exists)
@@ -157,6 +195,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     const int nchunks = c_end - c_begin;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));    // opaque 0: keeps the descriptor loads on the vector path
+    BX_STAMP_DECL;
+    BX_STAMP(-1);
 
     auto load_desc = [&](int k) -> i32x2 {                              // past the end: the item's first chunk (ignored)
         const int c = c_begin + (k < nchunks ? k : 0) + vzero;
@@ -173,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     // dump row v = (NPW/2) * hw + i  <->  node NPW * hw + (NPW/2) * half + i   (helper lanes 32*half .. 32*half + 31)
     constexpr int HN = BN / 2, HPW = NPW / 2;
     auto tail_half = [&](int half, auto rb_c) {          // rb_c: rows in flight per wave (fewer while the helpers still hold sums)
+        if (GHF_BXEXP & 32) return;
         const float* acc_lds = (const float*)smem;
         constexpr int CPL = D / 64;
         int col[CPL];
@@ -295,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // granules of a row are XOR-swizzled by (row & 15) as the consumers' fragment reads expect (message_hx.hip) ----
         auto dma_tile = [&](unsigned tile_off, int j, int which /*2: src ids, 3: dst ids*/, int rows, bool nt, int lane) {
             const unsigned ids = lds0 + meta_off(j) + 4 * (which * CRP);
+            if (GHF_BXEXP & 2) return;
             static_assert(RBW <= 6, "ids of a tile: one batched read");
             unsigned ia[6];
             int id[6];
@@ -304,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
             for (int i = 0; i < RBW; ++i) {
                 const int rb = hw + TW * i, row = 4 * rb + (lane >> 4);
+                if (4 * rb >= rows) continue;               // (uniform) a piece without live rows is not issued
                 const int g = (lane & 15) ^ (row & 15);
                 // dead rows: an offset past the end of the buffer (zeros, no memory access)
                 const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : 0x7FFFFF00;
@@ -334,7 +377,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // ---- fold chunk j's staged rows into the registers -------------------------------------------------------
         // Y [row][position], the two 32-position halves of a 64-position group swapped when (row >> 2) & 1 (the consumers'
         // ds_write_b64 of four row groups then touch every bank exactly twice)
-        auto fold = [&](int j, int rows, int lane) {
+        // Two parts, so that the helpers' work per stage matches the consumers' (tools/stamps_bx.py): fold_prep + the first
+        // half of the units in stage (k,0), the second half in stage (k,1); a per-wave flag in LDS tells the consumers, who
+        // overwrite Y at the end of stage (k,1), that the fold of the previous chunk's rows is complete.
+        auto fold_prep = [&](int j, int rows, int lane, int (&ri)[U]) {
             const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
             const unsigned Y = lds0 + Y_OFF;
             // 1. runs of equal destinations owned by this wave: add row r into row r + 1, ascending
@@ -356,9 +402,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                     lds_st_b64(pb, x + y);
                 }
             }
-            // 2. every owner lane: the staged row of its node, if any
+            // 2. every owner lane: the staged row of its node, if any; then the table is free for the next chunk
             static_assert(U <= 12, "table reads: two batches of six");
-            int ri[12];
 #pragma unroll
             for (int k0 = 0; k0 < U; k0 += 6) {
                 unsigned ta[6];
@@ -367,24 +412,30 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 for (int k = 0; k < 6; ++k) ta[k] = lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + (U * lane + (k0 + k < U ? k0 + k : 0)) / NU);
                 lds_ld_b32_x6(ta, tv);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) ri[k0 + k] = tv[k];
+                for (int k = 0; k < 6; ++k)
+                    if (k0 + k < U) ri[k0 + k] = tv[k];
             }
+            table_clear(lane);
+        };
+        auto fold_units = [&](auto k_lo, auto k_hi, int lane, const int (&ri)[U]) {
+            constexpr int K0 = decltype(k_lo)::value, K1 = decltype(k_hi)::value;
+            const unsigned Y = lds0 + Y_OFF;
             // the unit's bytes in Y (a lane whose node has no row in this chunk reads — and adds — zeros: no branch)
             unsigned ua[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
+            for (int k = K0; k < K1; ++k) {
                 const int part = (U * lane + k) % NU, r = ri[k];
                 ua[k] = r >= 0 ? Y + (unsigned)r * (D * 4) + (unsigned)(((part * UW) ^ (((r >> 2) & 1) << 5)) * 4) : lds0 + ZERO_OFF;
             }
             // all 16-byte reads of the lane as one sequence, SB per step, RD steps in flight
-            constexpr int SB = GHF_BX_SB, RD = GHF_BX_RD, RPU = UW / 4, NRD = U * RPU, NST = NRD / SB;
+            constexpr int SB = GHF_BX_SB, RD = GHF_BX_RD, RPU = UW / 4, NRD = (K1 - K0) * RPU, NST = NRD / SB;
             static_assert(NRD % SB == 0, "reads per lane must be a multiple of the step");
             f32x4 y[RD][SB];
             auto issue = [&](int st, f32x4 (&dstv)[SB]) {
 #pragma unroll
                 for (int i = 0; i < SB; ++i) {
                     const int g = st * SB + i;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dstv[i]) : "v"(ua[g / RPU]), "n"(16 * (g % RPU)) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dstv[i]) : "v"(ua[K0 + g / RPU]), "n"(16 * (g % RPU)) : "memory");
                 }
             };
 #pragma unroll
@@ -401,14 +452,26 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(3 * SB) : "memory");
 #pragma unroll
                 for (int i = 0; i < SB; ++i) {
-                    const int g = st * SB + i, k = g / RPU, o = 4 * (g % RPU);
+                    const int g = st * SB + i, k = K0 + g / RPU, o = 4 * (g % RPU);
+#if GHF_BX_PK
+                    {   // two v_pk_add_f32 instead of four v_add_f32
+                        f32x2 lo2 = (f32x2){sums[k][o], sums[k][o + 1]} + (f32x2){y[st % RD][i][0], y[st % RD][i][1]};
+                        f32x2 hi2 = (f32x2){sums[k][o + 2], sums[k][o + 3]} + (f32x2){y[st % RD][i][2], y[st % RD][i][3]};
+                        sums[k][o] = lo2[0]; sums[k][o + 1] = lo2[1]; sums[k][o + 2] = hi2[0]; sums[k][o + 3] = hi2[1];
+                    }
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sums[k][o + e] += y[st % RD][i][e];
+#endif
                     // pin the sums behind this step: otherwise all reads are issued first (192 live registers) and the adds follow
                     asm volatile("" : "+v"(sums[k][o]), "+v"(sums[k][o + 1]), "+v"(sums[k][o + 2]), "+v"(sums[k][o + 3]));
                 }
             }
         };
+        constexpr int UH = (U + 1) / 2;                    // units folded in stage (k,0); the rest in stage (k,1)
+        using U0 = std::integral_constant<int, 0>;
+        using U1 = std::integral_constant<int, UH>;
+        using U2 = std::integral_constant<int, U>;
 
         // ---- prologue: descriptors of chunks 0..2 published, source rows of chunks 0 and 1 in their tiles ------------
         // Pipeline of a chunk j's descriptor: chunk_tab entry requested in stage (j-6,1), its words (source id, key) in
@@ -418,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         Words wd3{0, 0}, wd4{0, 0}, wd5{0, 0};             // words of chunks k + 3, k + 4, k + 5
         Scales sc3{1.f, 1.f}, sc4{1.f, 1.f};               // scales of chunks k + 3, k + 4
         table_clear(lane);
-        if (hw == 0 && lane < 32) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);
+        if (hw == 0 && lane < 32 + 4) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);      // zeros and the four flags behind them
         int prev_rows = 1;
         if (nchunks > 0) {
             i32x2 dd[6];
@@ -447,36 +510,63 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         i32x2 d6{0, 0};
+        int ri[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) ri[k] = -1;
         for (int k = 0; k < nchunks; ++k) {
             __builtin_amdgcn_s_barrier();                  // ---- stage (k,0)
+            BX_STAMP(0);
             const int l0 = opaque_lane(lane);
             dma_tile(P1_OFF, k, 3, ch[0].rows, false, l0);
-            if (k > 0) {
-                fold(k - 1, prev_rows, l0);
-                table_clear(l0);
+            BX_STAMP(1);
+            if (k > 0 && !(GHF_BXEXP & 8)) {
+                fold_prep(k - 1, prev_rows, l0, ri);
+                fold_units(U0{}, U1{}, l0, ri);
             }
-            // (behind the fold: the wait for d6 is also a wait for the source-row DMA issued before it)
+            BX_STAMP(2);
+            // (behind the fold — the empty statement keeps the scheduler from hoisting it: the wait for d6 is a wait for
+            // every DMA issued so far)
+            asm volatile("" : "+v"(d6));
             if (k > 0) ch[5] = decode(d6);
-            sc4 = load_scales(ch[4], wd4);
-            wd5 = load_words(ch[5], l0);
+            if (!(GHF_BXEXP & 64)) {
+                sc4 = load_scales(ch[4], wd4);
+                wd5 = load_words(ch[5], l0);
+            }
+            BX_STAMP(4);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the P1 pieces (and everything older) have landed
             BX_LGKM0();
+            BX_STAMP(3);
             __builtin_amdgcn_s_barrier();                  // ---- stage (k,1)
+            BX_STAMP(0);
             const int l1 = opaque_lane(lane);
-            dma_tile(P0_OFF + (k & 1) * TILE, k + 2, 2, ch[2].rows, true, l1);
-            table_write(k, ch[0].rows, l1);
-            d6 = load_desc(k + 6);
-            publish(k + 3, ch[3], wd3, sc3, l1);
+            // the descriptor values move up one place BEFORE this stage's DMA is issued: the wait for the newest of them
+            // (requested a stage ago) is then not a wait for the DMA
+            if (!(GHF_BXEXP & 64)) publish(k + 3, ch[3], wd3, sc3, l1);
             wd3 = wd4;
             sc3 = sc4;
             wd4 = wd5;
+            asm volatile("" : "+v"(wd3.src), "+v"(wd3.key), "+v"(sc3.u), "+v"(sc3.v), "+v"(wd4.src), "+v"(wd4.key));
+            BX_STAMP(4);
+            dma_tile(P0_OFF + (k & 1) * TILE, k + 2, 2, ch[2].rows, true, l1);
+            BX_STAMP(1);
+            if (k > 0 && !(GHF_BXEXP & 8)) fold_units(U1{}, U2{}, l1, ri);
+            BX_LGKM0();
+            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k);     // the rows of chunk k - 1 are folded: Y may be overwritten
+            BX_STAMP(2);
+            if (!(GHF_BXEXP & 64)) table_write(k, ch[0].rows, l1);
+            d6 = load_desc(k + 6);
             prev_rows = ch[0].rows;
 #pragma unroll
             for (int j = 0; j < 5; ++j) ch[j] = ch[j + 1];
             BX_LGKM0();
+            BX_STAMP(4);
         }
         __builtin_amdgcn_s_barrier();                      // ---- epilogue stage: the last chunk's rows
-        if (nchunks > 0) fold(nchunks - 1, prev_rows, opaque_lane(lane));
+        if (nchunks > 0 && !(GHF_BXEXP & 8)) {
+            const int le = opaque_lane(lane);
+            fold_prep(nchunks - 1, prev_rows, le, ri);
+            fold_units(U0{}, U2{}, le, ri);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
         BX_LGKM0();
         for (int half = 0; half < 2; ++half) {
@@ -496,6 +586,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             if (half == 0) tail_half(0, std::integral_constant<int, 4>{});
             else tail_half(1, std::integral_constant<int, 12>{});
         }
+        BX_STAMP(6);
+        BX_STAMP_FLUSH();
     } else {
         // =============================================== CONSUMERS ===============================================
         // B fragments (GHF_WLAYOUT_SPLIT2H): Wh[r][o/16][kk/32][piece][lane][8] fp16, then one float 2^-s per relation
@@ -515,31 +607,48 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         };
         f32x4 acc[MTC][NTW];
         const int arow = c16 * ROWB;
-        auto compute_stage = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+        // One instance per number of live row tiles: no branch, no LDS read and no zeroing for dead tiles inside the loop
+        // (a uniform branch per (k-step, tile) position cost the MFMA stream a fetch bubble each)
+        auto compute_stage = [&](auto mt_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
                                  const float (&bias_v)[NTW]) {
+            constexpr int MT = decltype(mt_c)::value;
             f32x4 part[MTC][NTW];
 #pragma unroll
-            for (int m = 0; m < MTC; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) part[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 sc[MTC];
-#pragma unroll
-            for (int m = 0; m < MTC; ++m) sc[m] = *(const f32x4*)(meta + ph * CRP + m * 16 + 4 * q);
-            i32x4 a[3][NPL];
+            f32x4 sc[MTC];                                  // the rows' scales: read during the last k-step (short live range)
+            // A fragments of (k-step, tile) positions p .. p + AD: with the helpers' DMA writes and fold reads on the LDS a read
+            // takes ~250 cycles, a position's six MFMAs 96 (tools/stamps_bx.py: two positions ahead left the stage
+            // latency-bound)
+            constexpr int AD = GHF_BX_AD;
+            i32x4 a[AD + 1][NPL];
             auto lda = [&](int j, int m, i32x4 (&dst)[NPL]) {
                 const char* src = Abuf + arow + (((4 * j + q) ^ c16) << 4) + m * 16 * ROWB;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) dst[pl] = *(const i32x4*)(src + pl * PLANE);
             };
-            lda(0, 0, a[0]);
-            lda(0, 1, a[1]);
+#pragma unroll
+            for (int p = 0; p < AD && p < KS * MT; ++p) lda(p / MT, p % MT, a[p]);
+            BX_STAMP(4);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
+                if (j == KS - 1) {
 #pragma unroll
-                for (int m = 0; m < MTC; ++m) {
-                    const int p = j * MTC + m, cur = p % 3;
-                    if (p + 2 < KS * MTC) lda((p + 2) / MTC, (p + 2) % MTC, a[(p + 2) % 3]);
-                    if (m < mt) {
+                    for (int m = 0; m < MT; ++m) sc[m] = *(const f32x4*)(meta + ph * CRP + m * 16 + 4 * q);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int p = j * MT + m, cur = p % (AD + 1);
+                    if (p + AD < KS * MT) lda((p + AD) / MT, (p + AD) % MT, a[(p + AD) % (AD + 1)]);
+                    if (GHF_BXEXP & 4) {                                    // operands stay alive (no DCE of the loads)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) asm volatile("" ::"v"(a[cur][pl]));
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                            for (int pl = 0; pl < NPL; ++pl) asm volatile("" ::"v"(b[j][t][pl]));
+                    } else {
 #pragma unroll
                         for (int t = 0; t < NTW; ++t) {
                             auto fma = [&](int pa, int pb) {
@@ -553,12 +662,13 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                load_b_step(r_next, ph_next, j);
+                BX_STAMP(5);
+                if (!(GHF_BXEXP & 1)) load_b_step(r_next, ph_next, j);
                 __builtin_amdgcn_sched_barrier(0);
+                BX_STAMP(7);
             }
 #pragma unroll
-            for (int m = 0; m < MTC; ++m) {
-                if (m >= mt) continue;
+            for (int m = 0; m < MT; ++m) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float f = sc[m][s] * wscale;
@@ -566,6 +676,20 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                     for (int t = 0; t < NTW; ++t) acc[m][t][s] = fmaf(part[m][t][s], f, ph == 0 ? bias_v[t] : acc[m][t][s]);
                 }
             }
+            // (the tiles this instance does not compute: defined here, so that their old values need not survive the stage)
+#pragma unroll
+            for (int m = MT; m < MTC; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        auto stage_for = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+                             const float (&bias_v)[NTW]) {
+            // three instances: all tiles, one fewer, two fewer (shorter chunks — 7 % at C3 — run the last one: their dead
+            // tiles cost MFMAs on stale rows that are never written)
+            static_assert(MTC >= 3, "three compute_stage instances");
+            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
+            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
+            else compute_stage(std::integral_constant<int, MTC - 2>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
         };
         // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1)
         const unsigned ybase = lds0 + Y_OFF + (unsigned)(4 * q) * (D * 4) + (unsigned)(((32 * tw + 2 * c16) ^ ((q & 1) << 5)) * 4);
@@ -602,18 +726,37 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             const int mt = (ch.rows + 15) >> 4;
             const int* meta = (const int*)(smem + meta_off(k));
             __syncthreads();                               // stage (k,0): phase 0
+            BX_STAMP(0);
             const BxChunk nx = decode(dn);
-            compute_stage(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, ch.r, 1, bias_v);
+            stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, ch.r, 1, bias_v);
+            BX_STAMP(1);
             __syncthreads();                               // stage (k,1): phase 1, then the chunk's rows are staged
+            BX_STAMP(0);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
-            compute_stage(mt, 1, smem + P1_OFF, meta, wscale, nx.r, 0, bias_v);
-            write_rows(mt);
+            stage_for(mt, 1, smem + P1_OFF, meta, wscale, nx.r, 0, bias_v);
+            BX_STAMP(2);
+            if (k > 0 && !(GHF_BXEXP & 8)) {                // Y is free once every helper wave has folded chunk k - 1's rows
+                for (;;) {
+                    i32x4 f;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF) : "memory");
+                    const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                    if (__builtin_amdgcn_readfirstlane(lo) >= k) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (!(GHF_BXEXP & 16)) write_rows(mt);
+            else
+#pragma unroll
+                for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) asm volatile("" ::"v"(acc[m][t]));
             ch = nx;
             wscale = wscale_n;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) bias_v[t] = bias_n[t];
             BX_LGKM0();
+            BX_STAMP(3);
         }
         __syncthreads();                                   // epilogue stage
         for (int half = 0; half < 2; ++half) {
@@ -621,15 +764,16 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             __syncthreads();
             tail_half(half, std::integral_constant<int, 12>{});
         }
+        BX_STAMP(6);
+        BX_STAMP_FLUSH();
     }
-
 }
 
 template <int D>
 static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     using C = BxCfg<D>;
     constexpr int CRP = 16 * C::MTC;
-    constexpr size_t lds = (size_t)4 * 2 * C::CR * (D * 2) + (size_t)C::BN * 4 + 4 * (4 * CRP + 4) * 4 + 1024 + 128;
+    constexpr size_t lds = (size_t)4 * 2 * C::CR * (D * 2) + (size_t)C::BN * 4 + 4 * (4 * CRP + 4) * 4 + 1024 + 128 + 16;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((size_t)(C::BN / 2) * D * 4 <= (size_t)3 * 2 * C::CR * (D * 2), "the tail's dump of half a block must fit the three A tiles");
     GHF_REQUIRE(a.block_nodes == C::BN, "message(bx): plan block_nodes=%d, kernel for d=%d needs %d", a.block_nodes, D, C::BN);
@@ -670,3 +814,9 @@ int launch_message_bx(const MsgArgs& a, hipStream_t stream) {
 }
 
 }  // namespace ghf
+
+#ifdef GHF_STAMPS
+extern "C" int ghf_debug_read_stamps_bx(unsigned long long* host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_stamp_buf), count * sizeof(unsigned long long));
+}
+#endif

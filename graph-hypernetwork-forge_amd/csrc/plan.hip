@@ -19,6 +19,7 @@
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 namespace ghf {
 
@@ -113,13 +114,16 @@ __global__ void plan_heads_kernel(const uint32_t* __restrict__ sorted_key, const
     sorted_src[e] = (int32_t)(((uint32_t)sorted_src[e] & (uint32_t)SRC_MASK) | ((uint32_t)head << SRC_BITS));
 }
 
-// items per block: 1, or ceil(chunks / T) for a heavy block; slots = items of split blocks only
-__global__ void plan_item_count_kernel(const int32_t* __restrict__ blk_chunk_off, int64_t NB, int T,
-                                       int32_t* __restrict__ ni, int32_t* __restrict__ nslot) {
+// items per block: 1, or ceil(chunks / T) for a heavy block; slots = items of split blocks only.
+// The blocks of the last, partly filled round of workgroups (tail0 .. NB-1; one workgroup per CU per round) are cut into
+// tail_items items each, so that the round's work spreads over the CUs that would otherwise idle through it.
+__global__ void plan_item_count_kernel(const int32_t* __restrict__ blk_chunk_off, int64_t NB, int T, int64_t tail0,
+                                       int tail_items, int32_t* __restrict__ ni, int32_t* __restrict__ nslot) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= NB) return;
     const int n = blk_chunk_off[b + 1] - blk_chunk_off[b];
-    const int k = n > T ? (n + T - 1) / T : 1;
+    int k = n > T ? (n + T - 1) / T : 1;
+    if (b >= tail0 && tail_items > k) k = n / 8 < tail_items ? (n / 8 > k ? n / 8 : k) : tail_items;   // >= 8 chunks per item
     ni[b] = k;
     nslot[b] = k > 1 ? k : 0;
 }
@@ -163,9 +167,30 @@ static size_t scan_temp_bytes(int64_t n) {
 
 static int64_t num_segments(int64_t N, int R, int BN) { return BN == 1 ? N : cdiv(N, BN) * R; }
 
+// The last round of workgroups: with NB blocks on `cus` compute units, NB % cus blocks remain for a last round that keeps
+// only as many CUs busy.  When that is less than half of them (and there is more than one round), each of these blocks
+// becomes floor(cus / remainder) <= 8 work items.  GHF_TAIL_SPLIT=0 turns it off.
+static int tail_split(int64_t NB, int64_t* tail0) {
+    static const int cus = [] {
+        const char* e = getenv("GHF_TAIL_SPLIT");
+        if (e && atoi(e) == 0) return 0;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    }();
+    *tail0 = NB;
+    if (cus <= 0 || NB <= cus) return 1;
+    const int64_t rem = NB % cus;
+    if (rem == 0 || rem * 2 > cus) return 1;
+    *tail0 = NB - rem;
+    const int64_t s = cus / rem;
+    return (int)(s > 8 ? 8 : s);
+}
+
 int64_t plan_max_items(int64_t N, int64_t E, int R, int BN, int CR, int T) {
     if (BN == 1 || CR <= 0 || T <= 0) return 0;
-    return cdiv(N, BN) + plan_max_chunks(N, E, R, BN, CR) / T + 1;      // every block one item, heavy ones chunks/T more
+    // every block one item, heavy ones chunks/T more, the last round's blocks up to 8 each (at most one per CU)
+    return cdiv(N, BN) + plan_max_chunks(N, E, R, BN, CR) / T + 1 + 1024;
 }
 
 int64_t plan_max_chunks(int64_t N, int64_t E, int R, int BN, int CR) {
@@ -249,7 +274,9 @@ int launch_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t 
         int32_t* ioff = (int32_t*)p;             p += align_up((size_t)(NB + 1) * 4, 256);
         int32_t* soff = (int32_t*)p;
         const int gb = (int)((NB + 1 + 255) / 256);
-        plan_item_count_kernel<<<gb, 256, 0, stream>>>(blk_chunk_off, NB, T, ni, nslot);
+        int64_t tail0 = NB;
+        const int tail_items = tail_split(NB, &tail0);
+        plan_item_count_kernel<<<gb, 256, 0, stream>>>(blk_chunk_off, NB, T, tail0, tail_items, ni, nslot);
         GHF_LAUNCH_CHECK();
         GHF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int32_t*)ni, ioff, (int)NB, stream));
         GHF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int32_t*)nslot, soff, (int)NB, stream));

@@ -38,10 +38,12 @@ def test_native_library_is_loaded():
     lib = _native.load()
     assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
-    assert _native.message_config(128) == (216, _native.WLAYOUT_SPLIT2H, 48, 128)
+    assert _native.message_config(128) == (384, _native.WLAYOUT_SPLIT2H, 76, 128)
     assert _native.message_config(64) == (216, _native.WLAYOUT_FRAG16, 48, 128)
     assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
     try:
+        os.environ["GHF_KERNEL"] = "hx"
+        assert _native.message_config(128) == (216, _native.WLAYOUT_SPLIT2H, 48, 128)
         os.environ["GHF_KERNEL"] = "pp"
         assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48, 128)
         os.environ["GHF_KERNEL"] = "sx"
