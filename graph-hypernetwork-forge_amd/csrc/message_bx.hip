@@ -172,9 +172,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr int RBW = (RBN + TW - 1) / TW;  // pieces per helper wave and plane
     constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
     static_assert(NTW == 2 && CR % 4 == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
-    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 3 * TILE, TAB_OFF = 4 * TILE, META_OFF = TAB_OFF + BN * 4,
+    // P0[2] source-row tiles, P1[2] destination-row tiles; a chunk's staged rows Y overwrite its own P1 tile
+    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, TAB_OFF = 4 * TILE, META_OFF = TAB_OFF + BN * 4,
                        DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: 128 bytes of zeros
-                       FLAG_OFF = ZERO_OFF + 128;         // FLAG: per helper wave, the number of chunks whose rows it has folded
+                       FLAG_OFF = ZERO_OFF + 128;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;       // LDS byte address of smem (0 unless static LDS exists)
@@ -212,83 +213,110 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     // ---- fused tail from LDS (both roles; the helpers dump their registers first, NPW / 2 nodes per wave at a time) ----
     // dump row v = (NPW/2) * hw + i  <->  node NPW * hw + (NPW/2) * half + i   (helper lanes 32*half .. 32*half + 31)
     constexpr int HN = BN / 2, HPW = NPW / 2;
-    auto tail_half = [&](int half, auto rb_c) {          // rb_c: rows in flight per wave (fewer while the helpers still hold sums)
+    // 16 lanes per row (a wave works on four rows at a time), eight adjacent columns per lane: every load and store is
+    // 16 bytes per lane, and a row reduction is four DPP steps inside its 16-lane row — for four rows at once.  (One wave
+    // per row, two columns per lane, took 1,800 cycles per row: ~110 dependent instructions, 2- and 4-byte stores.)
+    auto tail_half = [&](int half, auto gb_c) {          // gb_c: four-row groups in flight per wave
         if (GHF_BXEXP & 32) return;
-        const float* acc_lds = (const float*)smem;
-        constexpr int CPL = D / 64;
-        int col[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) col[c] = 32 * (lane >> 4) + 16 * c + (lane & 15);
+        const float* acc_lds = (const float*)smem;       // dump rows, natural column order
+        const int sub = lane >> 4, c0 = 8 * (lane & 15);
         auto node_of = [&](int v) -> int { return (v / HPW) * NPW + half * HPW + (v % HPW); };   // block-local node of dump row v
-        if (slot >= 0) {                               // one item of a split block: raw sums (column order) to my slot
+        auto row_sum = [&](float v) -> float {           // over the 16 lanes of a row, result in each of them
+            v += dpp_take<0xB1, 0xF>(v);
+            v += dpp_take<0x4E, 0xF>(v);
+            v += dpp_take<0x141, 0xF>(v);
+            v += dpp_take<0x140, 0xF>(v);
+            return v;
+        };
+        auto row_max = [&](float v) -> float {           // non-negative values
+            v = fmaxf(v, dpp_take<0xB1, 0xF>(v));
+            v = fmaxf(v, dpp_take<0x4E, 0xF>(v));
+            v = fmaxf(v, dpp_take<0x141, 0xF>(v));
+            v = fmaxf(v, dpp_take<0x140, 0xF>(v));
+            return v;
+        };
+        constexpr int NG = HN / 4;                        // four-row groups of this half
+        if (slot >= 0) {                                  // one item of a split block: raw sums to my slot
             float* __restrict__ ps = partial + (size_t)slot * BN * D;
-            for (int v = w; v < HN; v += NWV)
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) ps[(size_t)node_of(v) * D + col[c]] = acc_lds[v * D + lane * CPL + c];
+            for (int g = w; g < NG; g += NWV) {
+                const int v = 4 * g + sub;
+                const f32x4 a0 = *(const f32x4*)(acc_lds + v * D + c0), a1 = *(const f32x4*)(acc_lds + v * D + c0 + 4);
+                float* __restrict__ o = ps + (size_t)node_of(v) * D + c0;
+                *(f32x4*)o = a0;
+                *(f32x4*)(o + 4) = a1;
+            }
             return;
         }
-        float gm[CPL], bt[CPL];
+        float gm[8], bt[8];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            gm[c] = no_tail ? 1.f : gamma[col[c]];
-            bt[c] = no_tail ? 0.f : beta[col[c]];
+        for (int c = 0; c < 8; ++c) {
+            gm[c] = no_tail ? 1.f : gamma[c0 + c];
+            bt[c] = no_tail ? 0.f : beta[c0 + c];
         }
-        constexpr int RB = decltype(rb_c)::value;
-        for (int v0 = w; v0 < HN; v0 += NWV * RB) {
-            float x[RB][CPL], inv[RB];
+        constexpr int GB = decltype(gb_c)::value;
+        for (int g0 = w; g0 < NG; g0 += NWV * GB) {
+            f32x4 x[GB][2];
+            float inv[GB];
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const int v = v0 + rb * NWV;
-                const int nl = node_of(v < HN ? v : HN - 1);
+            for (int gb = 0; gb < GB; ++gb) {
+                const int g = g0 + gb * NWV;
+                const int nl = node_of(4 * (g < NG ? g : NG - 1) + sub);
                 const int64_t node = node0 + (nl < nrows ? nl : nrows - 1);
                 const int deg = indeg[node];
-                inv[rb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) x[rb][c] = no_tail ? 0.f : h[(size_t)node * D + col[c]];
+                inv[gb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
+                const float* __restrict__ hp = h + (size_t)node * D + c0;
+                x[gb][0] = no_tail ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)hp;
+                x[gb][1] = no_tail ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4);
             }
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const int v = v0 + rb * NWV;
-                const int vc = v < HN ? v : HN - 1;
-                const int nl = node_of(vc);
-                const bool live = v < HN && nl < nrows;
+            for (int gb = 0; gb < GB; ++gb) {
+                const int g = g0 + gb * NWV;
+                const int v = 4 * (g < NG ? g : NG - 1) + sub;
+                const int nl = node_of(v);
+                const bool live = g < NG && nl < nrows;
+                const f32x4 a0 = *(const f32x4*)(acc_lds + v * D + c0), a1 = *(const f32x4*)(acc_lds + v * D + c0 + 4);
+                float y[8];
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const float a = acc_lds[vc * D + lane * CPL + c] * inv[rb];
-                    x[rb][c] = no_tail ? a : fmaxf(a + x[rb][c], 0.f);
-                    s += x[rb][c];
+                for (int c = 0; c < 8; ++c) {
+                    const float a = (c < 4 ? a0[c] : a1[c - 4]) * inv[gb];
+                    y[c] = no_tail ? a : fmaxf(a + x[gb][c >> 2][c & 3], 0.f);
+                    s += y[c];
                 }
                 if (!no_tail) {
-                    const float mean = wave_sum(s) * (1.0f / D);
+                    const float mean = row_sum(s) * (1.0f / D);
                     float var = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) { const float t = x[rb][c] - mean; var += t * t; }
-                    const float rstd = 1.0f / sqrtf(wave_sum(var) * (1.0f / D) + eps);
+                    for (int c = 0; c < 8; ++c) { const float t = y[c] - mean; var += t * t; }
+                    const float rstd = 1.0f / sqrtf(row_sum(var) * (1.0f / D) + eps);
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) x[rb][c] = (x[rb][c] - mean) * rstd * gm[c] + bt[c];
+                    for (int c = 0; c < 8; ++c) y[c] = (y[c] - mean) * rstd * gm[c] + bt[c];
                 }
                 float up = 1.f;
                 if (h_split_out) {                       // the same row cut into fp16 pieces, for the next layer's gathers
                     float mx = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) mx = fmaxf(mx, fabsf(x[rb][c]));
-                    const int sh = split2h_shift(wave_absmax(mx));
+                    for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fabsf(y[c]));
+                    const int sh = split2h_shift(row_max(mx));
                     up = pow2f(sh);
-                    if (lane == 0 && live) *(float*)((char*)h_split_out + (size_t)hsc_off + (size_t)(node0 + nl) * 4) = pow2f(-sh);
+                    if ((lane & 15) == 0 && live) *(float*)((char*)h_split_out + (size_t)hsc_off + (size_t)(node0 + nl) * 4) = pow2f(-sh);
                 }
                 if (live) {
-#pragma unroll
-                    for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + nl) * D + col[c]] = x[rb][c];
+                    float* __restrict__ o = h_out + (size_t)(node0 + nl) * D + c0;
+                    *(f32x4*)o = (f32x4){y[0], y[1], y[2], y[3]};
+                    *(f32x4*)(o + 4) = (f32x4){y[4], y[5], y[6], y[7]};
                     if (h_split_out) {
-                        _Float16* __restrict__ sp = (_Float16*)h_split_out + (size_t)(node0 + nl) * (NPL * D);
+                        _Float16* __restrict__ sp = (_Float16*)h_split_out + (size_t)(node0 + nl) * (NPL * D) + c0;
+                        f16x8 hi8, lo8;
 #pragma unroll
-                        for (int c = 0; c < CPL; ++c) {
+                        for (int c = 0; c < 8; ++c) {
                             _Float16 hi, lo;
-                            split2h(x[rb][c] * up, hi, lo);
-                            sp[col[c]] = hi;
-                            sp[D + col[c]] = lo;
+                            split2h(y[c] * up, hi, lo);
+                            hi8[c] = hi;
+                            lo8[c] = lo;
                         }
+                        *(f16x8*)sp = hi8;
+                        *(f16x8*)(sp + D) = lo8;
                     }
                 }
             }
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // overwrite Y at the end of stage (k,1), that the fold of the previous chunk's rows is complete.
         auto fold_prep = [&](int j, int rows, int lane, int (&ri)[U]) {
             const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
-            const unsigned Y = lds0 + Y_OFF;
+            const unsigned Y = lds0 + P1_OFF + (unsigned)(j & 1) * TILE;
             // 1. runs of equal destinations owned by this wave: add row r into row r + 1, ascending
 #pragma unroll
             for (int pass = 0; pass < (CR + 63) / 64; ++pass) {
@@ -417,9 +445,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             table_clear(lane);
         };
-        auto fold_units = [&](auto k_lo, auto k_hi, int lane, const int (&ri)[U]) {
+        auto fold_units = [&](int j, auto k_lo, auto k_hi, int lane, const int (&ri)[U]) {
             constexpr int K0 = decltype(k_lo)::value, K1 = decltype(k_hi)::value;
-            const unsigned Y = lds0 + Y_OFF;
+            const unsigned Y = lds0 + P1_OFF + (unsigned)(j & 1) * TILE;
             // the unit's bytes in Y (a lane whose node has no row in this chunk reads — and adds — zeros: no branch)
             unsigned ua[U];
 #pragma unroll
@@ -468,107 +496,113 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 }
             }
         };
-        constexpr int UH = (U + 1) / 2;                    // units folded in stage (k,0); the rest in stage (k,1)
         using U0 = std::integral_constant<int, 0>;
-        using U1 = std::integral_constant<int, UH>;
         using U2 = std::integral_constant<int, U>;
+        // wait until all four words at `flags` have reached v (the waves of one role run the same program: short waits)
+        auto wait_flags = [&](unsigned flags, int v) {
+            for (;;) {
+                i32x4 f;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(flags) : "memory");
+                const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                if (__builtin_amdgcn_readfirstlane(lo) >= v) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        };
 
-        // ---- prologue: descriptors of chunks 0..2 published, source rows of chunks 0 and 1 in their tiles ------------
-        // Pipeline of a chunk j's descriptor: chunk_tab entry requested in stage (j-6,1), its words (source id, key) in
-        // (j-5,0), its rows' scales in (j-4,0), published in (j-3,1); the values move up one place per chunk AFTER they have
-        // arrived (a register copy of a value still in flight would wait for it, and for the DMA issued before it).
-        BxChunk ch[6];                                     // ch[i] = chunk k + i
-        Words wd3{0, 0}, wd4{0, 0}, wd5{0, 0};             // words of chunks k + 3, k + 4, k + 5
-        Scales sc3{1.f, 1.f}, sc4{1.f, 1.f};               // scales of chunks k + 3, k + 4
+        // ---- one workgroup barrier per chunk.  During chunk k (between barriers k and k + 1):
+        //   consumers: phase 0 from P0[k&1], phase 1 from P1[k&1]; once all four have read that tile, the chunk's rows Y(k)
+        //              overwrite it
+        //   helpers:   DMA P0[(k+1)&1] <- source rows of chunk k+1 (HBM: a whole chunk to land); fold Y(k-1) out of
+        //              P1[(k-1)&1]; once all four have folded, DMA that tile <- destination rows of chunk k+1 (L2); table of
+        //              chunk k; descriptor of chunk k+2
+        // Descriptor pipeline of chunk j: chunk_tab entry requested during chunk j-5, words (source id, key) j-4, the rows'
+        // scales j-3, published j-2.  Values move up one place at the START of a chunk, when they have long arrived (a
+        // register copy of a value still in flight waits for it, and for every DMA issued before it).
+        BxChunk ch[5];                                     // ch[i] = chunk k + i
+        Words wdP{0, 0}, wdN{0, 0}, wdL{0, 0};             // words of chunks k+2 (to publish), k+3, k+4 (just requested)
+        Scales scP{1.f, 1.f}, scN{1.f, 1.f};               // scales of chunks k+2, k+3 (just requested)
+        i32x2 d5{0, 0};                                    // chunk_tab entry of chunk k+5 (just requested)
         table_clear(lane);
-        if (hw == 0 && lane < 32 + 4) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);      // zeros and the four flags behind them
+        if (hw == 0 && lane < 32 + 8) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);      // zeros and the eight flags behind them
         int prev_rows = 1;
         if (nchunks > 0) {
-            i32x2 dd[6];
+            i32x2 dd[5];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) dd[j] = load_desc(j);
+            for (int j = 0; j < 5; ++j) dd[j] = load_desc(j);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) ch[j] = decode(dd[j]);
-            Words wd[5];
-            Scales sc[4];
+            for (int j = 0; j < 5; ++j) ch[j] = decode(dd[j]);
+            Words wd[4];
+            Scales sc[3];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) wd[j] = load_words(ch[j], lane);
+            for (int j = 0; j < 4; ++j) wd[j] = load_words(ch[j], lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[j] = load_scales(ch[j], wd[j]);
+            for (int j = 0; j < 3; ++j) sc[j] = load_scales(ch[j], wd[j]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) publish(j, ch[j], wd[j], sc[j], lane);
-            wd3 = wd[3];
-            sc3 = sc[3];
-            wd4 = wd[4];
+            for (int j = 0; j < 2; ++j) publish(j, ch[j], wd[j], sc[j], lane);
+            wdP = wd[2];
+            scP = sc[2];
+            wdN = wd[3];
         }
         BX_LGKM0();
-        __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0..2 visible to all helper waves
+        __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0 and 1 visible to all helper waves
         // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
         if (nchunks > 0) {
             dma_tile(P0_OFF, 0, 2, ch[0].rows, true, lane);
-            dma_tile(P0_OFF + TILE, 1, 2, ch[1].rows, true, lane);
+            dma_tile(P1_OFF, 0, 3, ch[0].rows, false, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        i32x2 d6{0, 0};
         int ri[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) ri[k] = -1;
         for (int k = 0; k < nchunks; ++k) {
-            __builtin_amdgcn_s_barrier();                  // ---- stage (k,0)
+            __builtin_amdgcn_s_barrier();                  // ---- chunk k
             BX_STAMP(0);
             const int l0 = opaque_lane(lane);
-            dma_tile(P1_OFF, k, 3, ch[0].rows, false, l0);
+            if (k > 0) {                                   // everything requested during the last chunk has arrived
+                wdP = wdN;
+                scP = scN;
+                wdN = wdL;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ch[j] = ch[j + 1];
+                ch[4] = decode(d5);
+                asm volatile("" : "+v"(wdP.src), "+v"(wdP.key), "+v"(scP.u), "+v"(scP.v), "+v"(wdN.src), "+v"(wdN.key));
+            }
+            if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
+            BX_STAMP(4);
+            dma_tile(P0_OFF + ((k + 1) & 1) * TILE, k + 1, 2, ch[1].rows, true, l0);
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
                 fold_prep(k - 1, prev_rows, l0, ri);
-                fold_units(U0{}, U1{}, l0, ri);
+                fold_units(k - 1, U0{}, U2{}, l0, ri);
             }
-            BX_STAMP(2);
-            // (behind the fold — the empty statement keeps the scheduler from hoisting it: the wait for d6 is a wait for
-            // every DMA issued so far)
-            asm volatile("" : "+v"(d6));
-            if (k > 0) ch[5] = decode(d6);
-            if (!(GHF_BXEXP & 64)) {
-                sc4 = load_scales(ch[4], wd4);
-                wd5 = load_words(ch[5], l0);
-            }
-            BX_STAMP(4);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the P1 pieces (and everything older) have landed
             BX_LGKM0();
+            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k + 1);   // this wave is through with Y(k-1) and the table
+            BX_STAMP(2);
+            wait_flags(lds0 + FLAG_OFF, k + 1);
             BX_STAMP(3);
-            __builtin_amdgcn_s_barrier();                  // ---- stage (k,1)
-            BX_STAMP(0);
             const int l1 = opaque_lane(lane);
-            // the descriptor values move up one place BEFORE this stage's DMA is issued: the wait for the newest of them
-            // (requested a stage ago) is then not a wait for the DMA
-            if (!(GHF_BXEXP & 64)) publish(k + 3, ch[3], wd3, sc3, l1);
-            wd3 = wd4;
-            sc3 = sc4;
-            wd4 = wd5;
-            asm volatile("" : "+v"(wd3.src), "+v"(wd3.key), "+v"(sc3.u), "+v"(sc3.v), "+v"(wd4.src), "+v"(wd4.key));
-            BX_STAMP(4);
-            dma_tile(P0_OFF + (k & 1) * TILE, k + 2, 2, ch[2].rows, true, l1);
+            dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l1);
             BX_STAMP(1);
-            if (k > 0 && !(GHF_BXEXP & 8)) fold_units(U1{}, U2{}, l1, ri);
-            BX_LGKM0();
-            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k);     // the rows of chunk k - 1 are folded: Y may be overwritten
-            BX_STAMP(2);
-            if (!(GHF_BXEXP & 64)) table_write(k, ch[0].rows, l1);
-            d6 = load_desc(k + 6);
+            if (!(GHF_BXEXP & 64)) {
+                table_write(k, ch[0].rows, l1);
+                scN = load_scales(ch[3], wdN);
+                wdL = load_words(ch[4], l1);
+            }
+            d5 = load_desc(k + 5);
             prev_rows = ch[0].rows;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) ch[j] = ch[j + 1];
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // both tiles of chunk k+1 have landed (5 requests younger)
             BX_LGKM0();
             BX_STAMP(4);
         }
-        __builtin_amdgcn_s_barrier();                      // ---- epilogue stage: the last chunk's rows
+        __builtin_amdgcn_s_barrier();                      // ---- epilogue: the last chunk's rows
         if (nchunks > 0 && !(GHF_BXEXP & 8)) {
             const int le = opaque_lane(lane);
             fold_prep(nchunks - 1, prev_rows, le, ri);
-            fold_units(U0{}, U2{}, le, ri);
+            fold_units(nchunks - 1, U0{}, U2{}, le, ri);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
         BX_LGKM0();
+        BX_STAMP(5);
         for (int half = 0; half < 2; ++half) {
             __syncthreads();
             if ((lane >> 5) == half) {
@@ -576,17 +610,25 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 for (int k = 0; k < U; ++k) {
                     const int u = U * lane + k, nl = u / NU, part = u % NU;
                     const unsigned a = lds0 + (unsigned)(hw * HPW + (nl - half * HPW)) * (D * 4) + (unsigned)part * (UW * 4);
+                    // position 2x + t of a 32-position group is column 16t + x of it (the consumers' C layout): the dump is
+                    // in column order
+                    static_assert(UW == 32, "the dump's position -> column permutation is per 32-position unit");
+                    auto cv = [&](int c) -> float { return sums[k][2 * (c & 15) + (c >> 4)]; };
 #pragma unroll
                     for (int i = 0; i < UW / 4; ++i)
-                        lds_st_b128(a + 16 * i, (f32x4){sums[k][4 * i], sums[k][4 * i + 1], sums[k][4 * i + 2], sums[k][4 * i + 3]});
+                        lds_st_b128(a + 16 * i, (f32x4){cv(4 * i), cv(4 * i + 1), cv(4 * i + 2), cv(4 * i + 3)});
                 }
             }
             BX_LGKM0();
             __syncthreads();
-            if (half == 0) tail_half(0, std::integral_constant<int, 4>{});
-            else tail_half(1, std::integral_constant<int, 12>{});
+            if (half == 0) {
+                tail_half(0, std::integral_constant<int, 1>{});      // (the other half of the sums is still in registers)
+                BX_STAMP(6);
+            } else {
+                tail_half(1, std::integral_constant<int, 3>{});
+                BX_STAMP(7);
+            }
         }
-        BX_STAMP(6);
         BX_STAMP_FLUSH();
     } else {
         // =============================================== CONSUMERS ===============================================
@@ -692,8 +734,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             else compute_stage(std::integral_constant<int, MTC - 2>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
         };
         // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1)
-        const unsigned ybase = lds0 + Y_OFF + (unsigned)(4 * q) * (D * 4) + (unsigned)(((32 * tw + 2 * c16) ^ ((q & 1) << 5)) * 4);
-        auto write_rows = [&](int mt) {
+        const unsigned yoff = (unsigned)(4 * q) * (D * 4) + (unsigned)(((32 * tw + 2 * c16) ^ ((q & 1) << 5)) * 4);
+        auto write_rows = [&](int mt, unsigned ytile) {
+            const unsigned ybase = lds0 + ytile + yoff;
 #pragma unroll
             for (int m = 0; m < MTC; ++m) {
                 if (m >= mt) continue;
@@ -725,27 +768,25 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         for (int k = 0; k < nchunks; ++k) {
             const int mt = (ch.rows + 15) >> 4;
             const int* meta = (const int*)(smem + meta_off(k));
-            __syncthreads();                               // stage (k,0): phase 0
+            __syncthreads();                               // ---- chunk k
             BX_STAMP(0);
             const BxChunk nx = decode(dn);
             stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, ch.r, 1, bias_v);
             BX_STAMP(1);
-            __syncthreads();                               // stage (k,1): phase 1, then the chunk's rows are staged
-            BX_STAMP(0);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
-            stage_for(mt, 1, smem + P1_OFF, meta, wscale, nx.r, 0, bias_v);
+            stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, 0, bias_v);
             BX_STAMP(2);
-            if (k > 0 && !(GHF_BXEXP & 8)) {                // Y is free once every helper wave has folded chunk k - 1's rows
-                for (;;) {
-                    i32x4 f;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF) : "memory");
-                    const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
-                    if (__builtin_amdgcn_readfirstlane(lo) >= k) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
+            // the chunk's rows overwrite its destination-row tile once every consumer wave has read it
+            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k + 1);
+            for (;;) {
+                i32x4 f;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 16) : "memory");
+                const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
+                __builtin_amdgcn_s_sleep(1);
             }
-            if (!(GHF_BXEXP & 16)) write_rows(mt);
+            if (!(GHF_BXEXP & 16)) write_rows(mt, P1_OFF + (k & 1) * TILE);
             else
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
@@ -762,7 +803,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         for (int half = 0; half < 2; ++half) {
             __syncthreads();
             __syncthreads();
-            tail_half(half, std::integral_constant<int, 12>{});
+            tail_half(half, std::integral_constant<int, 3>{});
+            if (half == 0) BX_STAMP(6);
         }
         BX_STAMP(6);
         BX_STAMP_FLUSH();
@@ -773,7 +815,7 @@ template <int D>
 static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     using C = BxCfg<D>;
     constexpr int CRP = 16 * C::MTC;
-    constexpr size_t lds = (size_t)4 * 2 * C::CR * (D * 2) + (size_t)C::BN * 4 + 4 * (4 * CRP + 4) * 4 + 1024 + 128 + 16;
+    constexpr size_t lds = (size_t)4 * 2 * C::CR * (D * 2) + (size_t)C::BN * 4 + 4 * (4 * CRP + 4) * 4 + 1024 + 128 + 32;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((size_t)(C::BN / 2) * D * 4 <= (size_t)3 * 2 * C::CR * (D * 2), "the tail's dump of half a block must fit the three A tiles");
     GHF_REQUIRE(a.block_nodes == C::BN, "message(bx): plan block_nodes=%d, kernel for d=%d needs %d", a.block_nodes, D, C::BN);

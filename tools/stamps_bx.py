@@ -26,8 +26,8 @@ buf = np.zeros(8192 * 8 * 8, dtype=np.uint64)
 fn = lib.ghf_debug_read_stamps_bx; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
-for role, sl, names in (("consumers", slice(0, 4), ["barrier wait", "phase-0: unscale+rest", "phase-1: unscale+rest", "staging writes", "stage prologue", "k-step MFMAs", "epilogue+tail", "B refill issue"]),
-                        ("helpers", slice(4, 8), ["barrier wait", "DMA issue", "fold+clear", "wait P1 pieces", "descriptor work", "-", "epilogue+tail", "-"])):
+for role, sl, names in (("consumers", slice(0, 4), ["barrier wait", "phase-0: unscale+rest", "phase-1: unscale+rest", "staging writes", "stage prologue", "k-step MFMAs", "epilogue + first half of the tail", "B refill issue"]),
+                        ("helpers", slice(4, 8), ["barrier wait", "DMA issue", "fold+clear", "wait for the other helpers", "descriptor work + DMA landing", "epilogue fold", "tail: first half", "tail: second half"])):
     x = st[:, sl]
     tot = x.sum()
     print(f"{role}: mean cycles per wave {x.sum(axis=2).mean():.0f}")
