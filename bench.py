@@ -64,8 +64,22 @@ def kern_name(plan, d):
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
-def cpu_baseline(cfg, budget_s=25.0):
-    """Time the oracle (reference op sequence, per-edge weight copies) on a bounded sample."""
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, budget_s=12.0, full=None):
+    """Time the oracle on the host cores: (i) the reference op sequence (per-edge [E,d,d] weight copies) on a bounded,
+    scaled-down sample — the reference cannot hold the full workload (2.6 TB at C3); (ii) the factorised restatement
+    (per-relation loop, O(E d) memory; oracle/hypergnn_oracle.py, validated against the reference through the golden
+    vectors) on the FULL workload, `full` = (node_features, edge_index, edge_texts) as numpy / list."""
     from graph_hypernetwork_forge_amd import synth
     from oracle import hypergnn_oracle as O
     d, R, L, T = cfg["d"], cfg["R"], cfg["L"], cfg["T"]
@@ -90,10 +104,26 @@ def cpu_baseline(cfg, budget_s=25.0):
     t0 = time.time()
     O.forward(params, kg.node_features, kg.edge_index, texts, variant="factorised")
     t_fact = time.time() - t0
-    return {"value": E / t, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"oracle forward (reference op sequence incl. per-edge [E,d,d] weight copies) on a scaled-down "
-                      f"instance of the workload: N={N}, E={E}, R={R}, d={d}, L={L}; median of {len(times)} runs",
-            "ms_per_forward": t * 1e3, "factorised_variant_edges_per_s": E / t_fact}
+    res = {"value": E / t, "unit": "edges/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+           "sample": f"oracle forward (reference op sequence incl. per-edge [E,d,d] weight copies) on a scaled-down "
+                     f"instance of the workload: N={N}, E={E}, R={R}, d={d}, L={L}; median of {len(times)} runs",
+           "ms_per_forward": t * 1e3, "factorised_variant_edges_per_s": E / t_fact}
+    if full is not None:
+        xf, eif, tf = full
+        paramsf = synth.hypergnn_params(T, xf.shape[1], d, L, seed=7)
+        runs = []
+        for _ in range(2):                                 # one warm-up (page faults, thread pool), one timed; a slow host
+            t0 = time.time()                               # (> 40 s per forward) keeps its only run
+            O.forward(paramsf, xf, eif, tf, variant="factorised")
+            runs.append(time.time() - t0)
+            if runs[-1] > 40.0:
+                break
+        res["full_size_factorised_edges_per_s"] = len(tf) / runs[-1]
+        res["full_size_factorised_s_per_forward"] = runs[-1]
+        res["full_size_sample"] = (f"oracle forward, factorised variant, on the whole workload (N={xf.shape[0]}, E={len(tf)}, "
+                                   f"R={R}, d={d}, L={L}), string -> id mapping included as in the reference; "
+                                   f"{'second of two runs' if len(runs) == 2 else 'single run'}")
+    return res
 
 
 def main():
@@ -106,6 +136,13 @@ def main():
     ap.add_argument("--hip-graph", action="store_true",
                     help="single GPU: a step replays the captured HIP graph of the warm forward (HyperGNN.graphed)")
     ap.add_argument("--kernel-reps", type=int, default=10, help="timed launches of the message kernel for the roofline")
+    ap.add_argument("--dist-mode", default=os.environ.get("GHF_DIST_MODE", "dst"), choices=["dst", "edges"],
+                    help="N > 1: destination shards + all-gather (default) or edge-range shards + reduction (BASELINE config 4 as written)")
+    ap.add_argument("--exchange", default=os.environ.get("GHF_DIST_EXCHANGE", "auto"), choices=["auto", "allgather", "pairs"],
+                    help="N > 1, dst mode: all_gather_into_tensor per chunk, pairwise send/recv, or the faster of the two "
+                         "(timed during the warm-up)")
+    ap.add_argument("--balance", default=os.environ.get("GHF_DIST_BALANCE", "rows"), choices=["rows", "edges"])
+    ap.add_argument("--weak", action="store_true", help="N > 1: one full workload per GPU (nodes and edges scale with N)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +163,10 @@ def main():
     from graph_hypernetwork_forge_amd.dist import ShardedHyperGNN
 
     _native.load()                                       # fail loudly if the HIP library is missing
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload])
+    if args.weak and world > 1:
+        cfg["N"], cfg["E"] = cfg["N"] * world, cfg["E"] * world
+        cfg["desc"] += f" x{world} (weak scaling: one such graph per GPU)"
     N, E, R, d, L, T = (cfg[k] for k in ("N", "E", "R", "d", "L", "T"))
 
     t0 = time.time()
@@ -140,7 +180,29 @@ def main():
     model = HyperGNN(text_dim=T, node_feat_dim=d, hidden_dim=d, num_layers=L).to(dev).eval().requires_grad_(False)
     t_setup = time.time() - t0
 
-    runner = ShardedHyperGNN(model) if world > 1 else None
+    runner = None
+    exchange_pick = None
+    if world > 1:
+        exch = args.exchange if args.dist_mode == "dst" and args.balance == "rows" else ("pairs" if args.balance == "edges" else "allgather")
+        if exch == "auto":
+            # both exchanges are built and timed for a few forwards; every rank takes the same decision (max over ranks)
+            cand = {}
+            for name in ("allgather", "pairs"):
+                r = ShardedHyperGNN(model, mode="dst", exchange=name, balance="rows")
+                with torch.no_grad():
+                    r(x, edge_index, edge_texts)
+                    dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(3):
+                        r(x, edge_index, edge_texts)
+                    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                cand[name] = (float(tt.item()) / 3 * 1e3, r)
+            exch = min(cand, key=lambda k: cand[k][0])
+            exchange_pick = {k: v[0] for k, v in cand.items()}
+            runner = cand[exch][1]
+        else:
+            runner = ShardedHyperGNN(model, mode=args.dist_mode, exchange=exch, balance=args.balance)
 
     graphed = model.graphed(x, edge_index, edge_texts) if (args.hip_graph and world == 1) else None
 
@@ -173,6 +235,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_step = elapsed / args.steps * 1e3
+
+    dist_detail = None
+    if world > 1:
+        # where a forward goes on every rank: the same forward with the exchange switched off (compute only), and with the
+        # kernels switched off (exchange only); "exposed" = what the full forward takes beyond its compute
+        def timed(profile, reps=3):
+            runner.profile = profile
+            step(); sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps * 1e3
+            runner.profile = "full"
+            return dt
+        comp, exch_ms = timed("compute"), timed("exchange")
+        step(); sync()
+        nbytes = runner.stats.get("bytes_recv", 0.0)
+        mine = torch.tensor([comp, exch_ms, max(0.0, ms_step - comp), nbytes], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        links = max(1, world - 1)                         # xGMI: one link per peer
+        dist_detail = {
+            "mode": runner.mode, "exchange": runner.exchange, "balance": runner.balance, "chunks": runner._spec.chunks,
+            "exchange_candidates_ms": exchange_pick,
+            "per_rank": [{"rank": r, "compute_ms": float(v[0]), "exchange_ms": float(v[1]), "exposed_exchange_ms": float(v[2]),
+                          "bytes_received_per_forward": float(v[3]),
+                          "gb_per_s_per_link": float(v[3]) / links / max(float(v[1]), 1e-9) / 1e6} for r, v in enumerate(allr)],
+            "note": "compute_ms / exchange_ms: the forward with the exchange / the kernels switched off (3 runs each); "
+                    "exposed = ms_per_step - compute_ms; per-link rate = bytes received / (world - 1) links / exchange_ms"}
 
     line = None
     if rank == 0:
@@ -260,13 +352,19 @@ def main():
             "config": {"workload": cfg["desc"], "nodes": N, "edges": E, "relations": R, "hidden_dim": d,
                        "layers": L, "text_dim": T, "plan": "cached (warm)",
                        "launch": "captured HIP graph replay" if graphed is not None else "one C-ABI call per kernel",
-                       "parallelism": "single GPU" if world == 1 else f"block-cyclic destination shards x{world}, chunked all-gather of h per layer overlapped with compute"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"block-cyclic destination shards x{world} ({runner.balance}-balanced), chunked {runner.exchange} exchange of h per layer overlapped with compute"
+                           if runner.mode == "dst" else f"edge-range shards x{world}, reduce-scatter of partial sums + all-gather per layer")},
             "cold_forward_ms": t_cold * 1e3, "setup_s": t_setup,
             "whole_forward_hbm_gbs": (L * layer_bytes(N, E, R, d) + 2 * N * d * 4) / (ms_step * 1e-3) / 1e9,
             "roofline": roofline,
         }
+        if dist_detail is not None:
+            line["dist"] = dist_detail
+            line["scaling"] = "weak" if args.weak else "strong"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            full = (x.cpu().numpy(), ei_np, edge_texts) if args.workload != "c5" else None    # (C5: 64M strings, 16 GB of h)
+            line["cpu_baseline"] = cpu_baseline(cfg, full=full)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
@@ -42,7 +42,7 @@ SIGNATURES = {
     "ghf_plan_max_items": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "ghf_plan_build": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp]),
-    "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+    "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                  _vp, _vp, _vp, _vp]),
     "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ghf_text_encode_fwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
@@ -146,6 +146,10 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
         raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
     if t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's stream (_stream): a tensor elsewhere would be read from the wrong GPU's queue
+        raise RuntimeError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "call torch.cuda.set_device(tensor.device) first (one process drives one GPU)")
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -189,17 +193,23 @@ def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, b
     return out
 
 
-def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], log_scales: torch.Tensor,
+def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], log_scales: Sequence[torch.Tensor],
                   T: int, Hh: int, num_hidden: int, d_in: int, d_out: int, layout: int,
                   out: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]] = None):
-    """head_params: flat list [head][layer][weight,bias]; returns (W_msg or Wfrag, W_self or None, bias)."""
+    """head_params: flat list [head][layer][weight,bias]; log_scales: the three 1-element tensors (W_msg, W_self, bias),
+    read in place; returns (W_msg or Wfrag, W_self or None, bias)."""
     lib = load()
     x = _req(text_emb, torch.float32, "text_emb")
     R = x.size(0)
     dev = x.device
     keep = [_req(p, torch.float32, "weight-generator parameter") for p in head_params]
     arr = (_vp * len(keep))(*[p.data_ptr() for p in keep])
-    ls = _req(log_scales, torch.float32, "log_scales")
+    if isinstance(log_scales, torch.Tensor):                  # a [3] tensor: three views of it
+        log_scales = [log_scales[i:i + 1] for i in range(3)]
+    ls_keep = [_req(t, torch.float32, "log_scale") for t in log_scales]
+    if len(ls_keep) != 3:
+        raise ValueError("weightgen_fwd: three log-scale tensors expected (W_msg, W_self, bias)")
+    ls = (_vp * 3)(*[t.data_ptr() for t in ls_keep])
     hidden_ws = torch.empty(3 * 2 * R * max(Hh, T, 1), dtype=torch.float32, device=dev)
     if out is None:
         if layout != WLAYOUT_NATURAL:                # one opaque buffer holds [W_msg; W_self] in the kernel's order
@@ -211,7 +221,7 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
         bias = torch.empty(R, d_out, dtype=torch.float32, device=dev)
     else:
         W_msg, W_self, bias = out
-    _check(lib.ghf_weightgen_fwd(_ptr(x), arr, _ptr(ls), R, T, Hh, num_hidden, d_in, d_out, layout,
+    _check(lib.ghf_weightgen_fwd(_ptr(x), arr, ls, R, T, Hh, num_hidden, d_in, d_out, layout,
                                  _ptr(hidden_ws), _ptr(W_msg), _ptr(W_self), _ptr(bias), _stream()),
            "ghf_weightgen_fwd")
     return W_msg, W_self, bias

@@ -119,7 +119,7 @@ int64_t plan_max_items(int64_t N, int64_t E, int R, int block_nodes, int chunk_r
 constexpr int SRC_BITS = 28;                          // sorted_src: node id in bits 0..27, run head in 28..31
 constexpr int32_t SRC_MASK = (1 << SRC_BITS) - 1;
 
-int launch_weightgen(const float* text_emb, const float* const* head_params, const float* log_scales,
+int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream);
 

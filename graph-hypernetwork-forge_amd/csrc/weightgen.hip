@@ -327,7 +327,7 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
     return GHF_OK;
 }
 
-int launch_weightgen(const float* text_emb, const float* const* head_params, const float* log_scales,
+int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream) {
     GHF_REQUIRE(R > 0 && T > 0 && d_in > 0 && d_out > 0, "weightgen: R, T, d_in, d_out must be positive");
@@ -378,17 +378,17 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
         if (mfma_ok && layout == GHF_WLAYOUT_SPLIT3) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_SPLIT3><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, rstride, out);
+                z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
         } else if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, rstride, out);
+                z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
         } else if (mfma_ok) {
             const int mtiles = (n_mat + 15) / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_NATURAL><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales + head, R, Hl, n_out, head, d_out, rstride, out);
+                z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
         } else {
-            wg_out_simple_kernel<<<(n_out + 3) / 4, 256, 0, stream>>>(z, W3, b3, log_scales + head, R, Hl, n_out,
+            wg_out_simple_kernel<<<(n_out + 3) / 4, 256, 0, stream>>>(z, W3, b3, log_scales[head], R, Hl, n_out,
                                                                       head, d_in, d_out, klayout, rstride, out);
         }
         GHF_LAUNCH_CHECK();

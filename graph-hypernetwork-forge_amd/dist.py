@@ -1,40 +1,44 @@
-"""Multi-GPU forward: one process per GPU, destination sharding, RCCL all-gather overlapped with compute.
+"""Multi-GPU forward: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).
 
-The path shards by DESTINATION node: a rank owns every in-edge of its rows, so each edge is
-owned by exactly one rank, the per-destination sums never cross ranks and the fused tail
-stays local.  The one real exchange step per layer is making the new h visible everywhere:
-an all-gather of rows over xGMI (half the bytes of the all-reduce an edge-range
-partition would need — SURVEY.md §8e).  The input projection is not exchanged: every rank computes it for all rows.  What travels is what the next layer's kernel gathers:
-for the default d = 128 kernel the rows already cut into their two fp16 pieces plus the row
-scales (written by the layer kernel's fused tail, 4 d + 4 bytes per row, the same volume as
-fp32), so no rank ever re-splits the full h; fp32 rows travel only after the last layer, and
-for the kernels that gather fp32 rows themselves.
+Two partitions of the path, behind one interface (`ShardedHyperGNN`):
 
-Ownership is block-cyclic so that the exchange overlaps the compute: the (padded) rows are cut
-into C chunks of G*S rows, and inside chunk c rank g owns rows [(c*G+g)*S, (c*G+g+1)*S)
-(S a multiple of the kernel's destination-block size).  A layer then runs as
-    for c in chunks:  launch the message kernel on my rows of chunk c          (compute stream)
-                      all-gather chunk c in place: a contiguous [G*S, d] slice   (comm stream)
-so the gather of chunk c travels while chunk c+1 computes, and only the last chunk's gather
-is exposed.  Weight generation (0.5 GFLOP) and the input projection (33 GFLOP) are recomputed on every rank
-instead of exchanged.
+* ``mode="dst"`` (default) — shards by DESTINATION node: a rank owns every in-edge of its rows, so the per-destination sums
+  never cross ranks and the fused tail stays local.  The one exchange per layer makes the new rows visible everywhere: an
+  all-gather of rows (half the bytes of the reduction an edge-range split needs).  What travels is what the next layer's
+  kernel gathers — for the d = 128 kernel the rows already cut into their two fp16 pieces plus the row scales (written by
+  the fused tail; the same volume as fp32), so no rank re-splits the full h; fp32 rows travel once, after the last layer.
+  Ownership is block-cyclic so that the exchange overlaps the compute: the rows are cut into C x G slots (BN-aligned), slot
+  c*G + g belongs to rank g, and a layer runs as
+      for c in chunks:  message kernel on my slot of chunk c (compute stream);  exchange of chunk c (comm stream)
+  so chunk c travels while chunk c + 1 computes.  Slots hold equal numbers of rows (``balance="rows"``) or about equal
+  numbers of in-edges (``balance="edges"``: power-law graphs, BASELINE config 5).
+  The exchange is either ``all_gather_into_tensor`` per chunk (RCCL picks ring or direct) or ``exchange="pairs"``: every
+  rank sends its slot straight to each peer (batched send/recv) — xGMI is a full mesh of point-to-point links, and a
+  pairwise exchange uses all seven of a GPU's links at once where a ring is bound by one.
+* ``mode="edges"`` — BASELINE.json's north-star split (config 4): every rank takes a contiguous range of the EDGE list
+  (balanced by construction), computes raw partial sums for all rows (GHF_FLAG_RAW_SUM), the partial sums are reduced
+  (reduce-scatter; all-reduce where the backend has no reduce-scatter), each rank divides by the global in-degree and runs
+  the tail (ghf_tail_fwd) on its rows, and the new rows are all-gathered.  Twice the exchange volume of ``dst`` and
+  chunks of 1/G the rows per weight fetch; kept for A/B (bench.py --dist-mode).
 
-The compute steps come from an `ops` object so that the sharding / exchange logic can be
-exercised on CPU with gloo (tests/test_dist_gloo.py injects the oracle there); the product
-default, NativeOps, calls the HIP library and nothing else.
+Weight generation (0.5 GFLOP) and the input projection (33 GFLOP) are recomputed on every rank instead of exchanged.
+The compute steps come from an `ops` object so that the sharding / exchange logic runs on CPU with gloo
+(tests/test_dist_gloo.py injects the oracle there); the product default, NativeOps, calls the HIP library and nothing else.
+Collective errors propagate: a failed RCCL call raises on the rank that saw it and the job exits non-zero.
 """
 
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 from . import _native
-from .plan import GraphPlan, build_plan, build_rs, relation_ids
+from .plan import GraphPlan, PlanCache, build_plan, build_rs, relation_ids
 
 
 @dataclass
@@ -44,31 +48,76 @@ class ShardSpec:
     rank: int
     block_nodes: int
     chunks: int                 # C
-    S: int                      # rows per (rank, chunk) slot; multiple of block_nodes
+    bounds: List[int]           # C*G + 1 row boundaries (multiples of block_nodes); slot c*G + g = [bounds[s], bounds[s+1])
+    uniform: bool = True        # every slot holds S rows (then the chunk all-gather is in place)
+
+    @property
+    def S(self) -> int:
+        return self.bounds[1] - self.bounds[0]
 
     @property
     def padded_rows(self) -> int:
-        return self.S * self.world * self.chunks
+        return max(self.bounds[-1], self.N)
 
     def slot(self, c: int, g: Optional[int] = None) -> Tuple[int, int]:
         """Row range [lo, hi) (clipped to N) that rank g owns in chunk c."""
         g = self.rank if g is None else g
-        lo = (c * self.world + g) * self.S
-        return min(self.N, lo), min(self.N, lo + self.S)
+        s = c * self.world + g
+        return min(self.N, self.bounds[s]), min(self.N, self.bounds[s + 1])
 
     def chunk_rows(self, c: int) -> Tuple[int, int]:
-        """Padded row range of chunk c (all ranks' slots): what one all-gather fills."""
-        return c * self.world * self.S, (c + 1) * self.world * self.S
+        """Row range of chunk c (all ranks' slots, padded): what one all-gather fills."""
+        return self.bounds[c * self.world], self.bounds[(c + 1) * self.world]
 
     def owned(self) -> List[Tuple[int, int]]:
         return [r for r in (self.slot(c) for c in range(self.chunks)) if r[1] > r[0]]
 
+    def owner_arg(self, device=None):
+        """What plan.build_plan needs to keep this rank's in-edges."""
+        if self.uniform:
+            return dict(owner=(self.S, self.world, self.rank))
+        return dict(owner_bounds=(torch.tensor(self.bounds, dtype=torch.int64), self.world, self.rank))
 
-def shard_spec(N: int, block_nodes: int, world: int, rank: int, chunks: int = 1) -> ShardSpec:
+
+def shard_spec(N: int, block_nodes: int, world: int, rank: int, chunks: int = 1,
+               block_edges: Optional[Sequence[int]] = None) -> ShardSpec:
+    """Block-cyclic slots of equal row count, or — with `block_edges[b]` = in-edges of destination block b — of about equal
+    in-edge count (every slot still a whole number of blocks; a slot may be empty)."""
     nb = -(-N // block_nodes)
     chunks = max(1, min(chunks, -(-nb // world)))          # no more chunks than blocks per rank
-    S = -(-nb // (world * chunks)) * block_nodes
-    return ShardSpec(N=N, world=world, rank=rank, block_nodes=block_nodes, chunks=chunks, S=S)
+    nslots = world * chunks
+    if block_edges is None:
+        S = -(-nb // nslots) * block_nodes
+        return ShardSpec(N=N, world=world, rank=rank, block_nodes=block_nodes, chunks=chunks,
+                         bounds=[s * S for s in range(nslots + 1)])
+    import numpy as np
+    be = np.asarray(block_edges, dtype=np.float64)
+    assert be.shape[0] == nb, "one in-edge count per destination block"
+    # a block's cost: its edges plus a constant per block (an empty block still runs its tail)
+    cost = be + max(1.0, be.sum() / max(nb, 1) * 0.05)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    total = cum[-1]
+    # chunks of equal cost; inside chunk c rank g takes blocks until its running total reaches its share of everything up
+    # to and including this chunk — a rank that a hub block pushed over its share gets less (or nothing) in later chunks
+    ccut = [int(np.searchsorted(cum, total * c / chunks, side="left")) for c in range(chunks + 1)]
+    ccut[0], ccut[-1] = 0, nb
+    cuts, have = [0], np.zeros(world)
+    for c in range(chunks):
+        lo, hi = max(ccut[c], cuts[-1]), max(ccut[c + 1], cuts[-1])
+        b = lo
+        for g in range(world):
+            target = cum[hi] / world                          # rank g's share of all blocks up to the end of this chunk
+            e = b
+            if g == world - 1:
+                e = hi
+            else:
+                while e < hi and have[g] + (cum[e + 1] - cum[b]) <= target + 0.5 * cost[e]:
+                    e += 1
+            have[g] += cum[e] - cum[b]
+            cuts.append(e)
+            b = e
+    return ShardSpec(N=N, world=world, rank=rank, block_nodes=block_nodes, chunks=chunks,
+                     bounds=[c * block_nodes for c in cuts], uniform=False)
 
 
 class NativeOps:
@@ -77,9 +126,9 @@ class NativeOps:
     def message_config(self, d: int):
         return _native.message_config(d)
 
-    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner) -> GraphPlan:
-        return build_plan(edge_index, rel_ids, unique, N, d, device, owner=owner,
-                          force_generic=_native.prefer_rs(d, len(unique)))
+    def build_plan(self, edge_index, rel_ids, unique, N, d, device, **shard) -> GraphPlan:
+        return build_plan(edge_index, rel_ids, unique, N, d, device,
+                          force_generic=_native.prefer_rs(d, len(unique)) and "edge_range" not in shard, **shard)
 
     def text_embs(self, model, unique: Sequence[str], device) -> torch.Tensor:
         return model.text_encoder(unique, device)
@@ -132,59 +181,127 @@ class NativeOps:
         _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(), norm.bias.detach(),
                                   norm.eps, h_out, row0=lo, rows=hi - lo, h_split=h_split, h_split_out=h_split_out)
 
+    # -- edge-range shards ------------------------------------------------------------------------------------
+    def layer_raw(self, model, l: int, weights, h, h_split, plan, partial) -> None:
+        """partial[v] = sum over THIS rank's edges into v of (h_u W_msg[r] + bias[r] + h_v W_self[r]) — no division, no tail."""
+        W, W_self, bias = weights
+        if plan.E == 0:
+            partial.zero_()
+            return
+        _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, None, None, 0.0, partial, h_split=h_split,
+                                  flags=_native.GHF_FLAG_RAW_SUM)
+
+    def scale_rows(self, sums: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:
+        return _native.rowscale(sums, inv)
+
+    def tail_rows(self, model, l: int, agg, h, h_out, lo: int, hi: int) -> None:
+        norm = model.layer_norms[l]
+        _native.tail_fwd(agg, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_out, row0=lo, rows=hi - lo)
+
 
 class ShardedHyperGNN:
-    """Runs ``HyperGNN.forward`` across the ranks of a process group; every rank returns the full [N, d]."""
+    """Runs ``HyperGNN.forward`` across the ranks of a process group; every rank returns the full [N, d].
 
-    def __init__(self, model, group: Optional[dist.ProcessGroup] = None, ops=None, chunks: Optional[int] = None) -> None:
+    mode: "dst" | "edges"; exchange: "allgather" | "pairs" (dst mode); balance: "rows" | "edges" (dst mode; "edges" implies
+    the pairwise exchange, whose messages may differ in size).  Defaults from GHF_DIST_MODE / GHF_DIST_EXCHANGE /
+    GHF_DIST_BALANCE / GHF_DIST_CHUNKS."""
+
+    def __init__(self, model, group: Optional[dist.ProcessGroup] = None, ops=None, chunks: Optional[int] = None,
+                 mode: Optional[str] = None, exchange: Optional[str] = None, balance: Optional[str] = None) -> None:
         self.model = model
         self.group = group
         self.ops = ops or NativeOps()
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.chunks = int(os.environ.get("GHF_DIST_CHUNKS", "4")) if chunks is None else chunks
+        self.mode = mode or os.environ.get("GHF_DIST_MODE", "dst")
+        self.balance = balance or os.environ.get("GHF_DIST_BALANCE", "rows")
+        self.exchange = exchange or os.environ.get("GHF_DIST_EXCHANGE", "allgather")
+        if self.mode not in ("dst", "edges") or self.balance not in ("rows", "edges") or self.exchange not in ("allgather", "pairs"):
+            raise ValueError(f"ShardedHyperGNN: mode={self.mode!r} balance={self.balance!r} exchange={self.exchange!r}")
+        if self.balance == "edges":
+            self.exchange = "pairs"
+        self.backend = dist.get_backend(group)
+        # what the backend offers is decided once, here — not by catching errors around a collective, which would hide real
+        # RCCL failures and let one rank leave a collective the others are still in
+        self._fused_gather = self.backend != "gloo"                      # all_gather_into_tensor / reduce_scatter_tensor
+        self.profile = "full"                                            # "compute" / "exchange": bench.py's breakdown passes
+        self.stats: Dict[str, float] = {}
         self._plan_key = None
         self._plan = None
         self._spec: Optional[ShardSpec] = None
+        self._inv = None
         self._comm_stream = None
         self._compute_streams: List = []
 
     # -- exchange ---------------------------------------------------------------------------------------
     def _gather_chunk(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
-        """All-gather of chunk c of a row-indexed buffer: rank g contributes its slot of the contiguous chunk slice.
-        In place when the buffer has the padded rows; a buffer of exactly N rows takes the chunk that reaches past N
-        through a staging copy."""
+        """Make every rank's slot of chunk c of a row-indexed buffer visible on every rank."""
+        if self.profile == "compute":
+            return
+        if self.exchange == "pairs" or not spec.uniform:
+            return self._gather_pairs(buf, spec, c)
         lo, hi = spec.chunk_rows(c)
-        if hi > buf.size(0):
+        if hi > buf.size(0):                                   # a buffer of exactly N rows: the chunk that reaches past N
             stage = torch.empty((hi - lo,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
             a, b = spec.slot(c)
             if b > a:
                 stage[a - lo: b - lo].copy_(buf[a:b])
-            self._gather_chunk(stage, ShardSpec(N=hi - lo, world=spec.world, rank=spec.rank, block_nodes=spec.block_nodes,
-                                                chunks=1, S=spec.S), 0)
+            sub = ShardSpec(N=hi - lo, world=spec.world, rank=spec.rank, block_nodes=spec.block_nodes, chunks=1,
+                            bounds=[g * spec.S for g in range(spec.world + 1)])
+            self._gather_chunk(stage, sub, 0)
             if buf.size(0) > lo:
                 buf[lo:].copy_(stage[: buf.size(0) - lo])
             return
         whole = buf[lo:hi]
         mine = buf[lo + spec.rank * spec.S: lo + (spec.rank + 1) * spec.S]
-        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+        self.stats["bytes_recv"] = self.stats.get("bytes_recv", 0.0) + (whole.numel() - mine.numel()) * whole.element_size()
+        if self._fused_gather:
+            dist.all_gather_into_tensor(whole, mine, group=self.group)
+        elif buf.is_cuda:
             # gloo moves host memory only: bounce (this is how the multi-rank GPU test runs two ranks on one card)
             parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(self.world)]
             dist.all_gather(parts, mine.cpu(), group=self.group)
             whole.copy_(torch.cat(parts), non_blocking=False)
-            return
-        try:
-            dist.all_gather_into_tensor(whole, mine, group=self.group)
-        except (RuntimeError, NotImplementedError):          # backends without the fused form
+        else:
             parts = [buf[lo + g * spec.S: lo + (g + 1) * spec.S] for g in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)
 
+    def _gather_pairs(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
+        """Pairwise exchange of chunk c: my slot to every peer, every peer's slot from it (one batch of sends/receives).
+        Only real rows travel (slots are clipped to N), and slots may differ in size."""
+        nrows = buf.size(0)
+        a, b = spec.slot(c)
+        a, b = min(a, nrows), min(b, nrows)
+        bounce = buf.is_cuda and self.backend == "gloo"
+        mine = buf[a:b].cpu() if bounce else buf[a:b]
+        ops, recvs = [], []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            lo, hi = spec.slot(c, p)
+            lo, hi = min(lo, nrows), min(hi, nrows)
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, mine, p, group=self.group))
+            if hi > lo:
+                dst = torch.empty((hi - lo,) + tuple(buf.shape[1:]), dtype=buf.dtype) if bounce else buf[lo:hi]
+                ops.append(dist.P2POp(dist.irecv, dst, p, group=self.group))
+                recvs.append((lo, hi, dst))
+                self.stats["bytes_recv"] = self.stats.get("bytes_recv", 0.0) + dst.numel() * dst.element_size()
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if bounce:
+            for lo, hi, t in recvs:
+                buf[lo:hi].copy_(t)
+
     def _run_chunked(self, bufs, spec: ShardSpec, compute_rows) -> None:
-        """compute_rows(lo, hi) fills my rows of a chunk in every buffer of `bufs`; the chunk's gathers overlap the next
+        """compute_rows(lo, hi) fills my rows of a chunk in every buffer of `bufs`; the chunk's exchange overlaps the next
         chunk's compute."""
         bufs = [bufs] if isinstance(bufs, torch.Tensor) else list(bufs)
         buf = bufs[0]
         on_gpu = buf.is_cuda
+        skip_compute = self.profile == "exchange"
         if on_gpu:
             # The chunks of one step are independent, so their kernels go to alternating streams: a rank's chunk is a
             # fraction of a chip-filling launch (145 workgroups at 8 GPUs x 4 chunks), and in one stream every launch
@@ -204,7 +321,7 @@ class ShardedHyperGNN:
                 lane = lanes[c % len(lanes)]
                 try:                                          # (set_stream, not the context manager: that one costs two
                     torch.cuda.set_stream(lane)               #  slow current_stream() lookups per use)
-                    if hi > lo:
+                    if hi > lo and not skip_compute:
                         compute_rows(lo, hi)
                     ready = torch.cuda.Event()
                     ready.record(lane)
@@ -215,7 +332,7 @@ class ShardedHyperGNN:
                 finally:
                     torch.cuda.set_stream(main)
             else:
-                if hi > lo:
+                if hi > lo and not skip_compute:
                     compute_rows(lo, hi)
                 for b in bufs:
                     self._gather_chunk(b, spec, c)
@@ -227,13 +344,27 @@ class ShardedHyperGNN:
 
     # -- plan -------------------------------------------------------------------------------------------
     def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], N: int, device) -> GraphPlan:
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, id(edge_texts), len(edge_texts), N)
-        if key != self._plan_key:
-            bn = self.ops.message_config(self.model.hidden_dim)[0]
-            spec = shard_spec(N, bn, self.world, self.rank, self.chunks)
+        key = PlanCache.key(edge_index, edge_texts, N, self.model.hidden_dim, device,
+                            extra=(self.world, self.rank, self.chunks, self.mode, self.balance))
+        if key != self._plan_key or os.environ.get("GHF_PLAN_CACHE") == "0":
+            d = self.model.hidden_dim
+            bn = self.ops.message_config(d)[0]
             unique, ids = relation_ids(edge_texts)
-            self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, self.model.hidden_dim,
-                                             device, (spec.S, self.world, self.rank))
+            E = edge_index.size(1)
+            if self.mode == "edges":
+                # contiguous ranges of the edge list; the rows are split evenly for the reduce-scatter / all-gather
+                spec = shard_spec(N, 1, self.world, self.rank, 1)
+                lo, hi = E * self.rank // self.world, E * (self.rank + 1) // self.world
+                self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, edge_range=(lo, hi))
+                deg = torch.bincount(edge_index[1].to(device), minlength=N).clamp_(min=1)
+                self._inv = (1.0 / deg.to(torch.float32)).contiguous()
+            else:
+                block_edges = None
+                if self.balance == "edges":
+                    nb = -(-N // bn)
+                    block_edges = torch.bincount(torch.div(edge_index[1], bn, rounding_mode="floor"), minlength=nb).cpu().tolist()
+                spec = shard_spec(N, bn, self.world, self.rank, self.chunks, block_edges)
+                self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, **spec.owner_arg())
             self._spec, self._plan_key, self._keep = spec, key, (edge_index, edge_texts)
         return self._plan
 
@@ -247,10 +378,13 @@ class ShardedHyperGNN:
         plan = self.plan_for(edge_index, edge_texts, N, device)
         spec = self._spec
         d = model.hidden_dim
+        self.stats = {"bytes_recv": 0.0}
         # fresh buffers per call (the result is a view of one of them); pad rows are exchanged but never read
         h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
         h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
+        if self.mode == "edges":
+            return self._forward_edges(node_features, plan, spec, text_embs, h, h_next)
         if self.ops.exchanges_split(plan):
             return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
         all_w, ready = self.ops.all_weights(model, text_embs, plan)
@@ -294,6 +428,42 @@ class ShardedHyperGNN:
                                                             h_split_out=out_split))
             h, h_next = h_next, h
             hs, hs_next = hs_next, hs
+        return h[:N]
+
+    def _forward_edges(self, node_features, plan, spec, text_embs, h, h_next) -> torch.Tensor:
+        """Edge-range shards (BASELINE config 4 as written): per layer raw partial sums over my edges -> reduction across
+        ranks -> my rows: mean, tail -> all-gather of the new rows."""
+        model, ops = self.model, self.ops
+        N, d, device = node_features.size(0), model.hidden_dim, node_features.device
+        G, S = self.world, spec.S
+        all_w, ready = ops.all_weights(model, text_embs, plan)
+        ops.input_proj(model, node_features, h[:N], None, plan)
+        partial = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
+        if spec.padded_rows > N:
+            partial[N:].zero_()
+        lo, hi = spec.slot(0)
+        for l in range(model.num_layers):
+            if ready is not None and ready[l] is not None:
+                torch.cuda.current_stream(device).wait_event(ready[l])
+            weights = all_w[l]
+            src_split = ops.split_rows(plan, h[:N])
+            if self.profile != "exchange":
+                ops.layer_raw(model, l, weights, h[:N], src_split, plan, partial[:N])
+            agg = h_next                                             # (scratch until the tail overwrites my rows of it)
+            if self.profile != "compute":
+                self.stats["bytes_recv"] += (G - 1) * S * d * 4
+                if self._fused_gather:
+                    dist.reduce_scatter_tensor(agg[self.rank * S:(self.rank + 1) * S], partial, group=self.group)
+                else:
+                    red = partial.cpu() if partial.is_cuda else partial
+                    dist.all_reduce(red, group=self.group)           # backends without reduce-scatter (gloo rehearsals)
+                    agg[self.rank * S:(self.rank + 1) * S].copy_(red[self.rank * S:(self.rank + 1) * S])
+            if hi > lo and self.profile != "exchange":
+                agg[lo:hi] = ops.scale_rows(agg[lo:hi], self._inv[lo:hi])
+                ops.tail_rows(model, l, agg[:N], h[:N], partial[:N], lo, hi)       # (partial: free after the reduction)
+                h_next[lo:hi].copy_(partial[lo:hi])
+            self._gather_chunk(h_next, spec, 0)
+            h, h_next = h_next, h
         return h[:N]
 
     __call__ = forward

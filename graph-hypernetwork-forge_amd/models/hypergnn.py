@@ -68,6 +68,10 @@ class TextEncoder(nn.Module):
             self._tokens[key] = hit
         return hit
 
+    def encode_one(self, text: str, device: torch.device) -> torch.Tensor:
+        """One string -> ``[text_dim]`` (reference hypergnn.py:73-77)."""
+        return self.forward([text], device)[0]
+
     def forward(self, texts: Sequence[str], device: torch.device) -> torch.Tensor:
         grad = wants_grad(self, self.char_emb.weight)
         ids, lens = self._token_matrix(texts, torch.device(device))
@@ -98,6 +102,11 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.output = model.forward_planned(self.input, plan)
+        # The captured launches hold raw device pointers into the plan's arrays (and its scratch), the relation strings'
+        # token matrices and the parameters; the plan cache and the token cache are small LRUs, so this object keeps its
+        # own references — evicting the plan elsewhere must not free memory a replay still reads.
+        self._keep = (model, plan, plan.rs, plan._partial, None if plan.rs is None else (plan.rs._Y, plan.rs._P),
+                      model.text_encoder._token_matrix(plan.unique_texts, dev))
 
     def replay(self, node_features: Optional[torch.Tensor] = None) -> torch.Tensor:
         if node_features is not None:

@@ -99,8 +99,9 @@ class WeightGenerator(nn.Module):
         dims = (self.text_dim, self.hidden_dim, self.num_hidden, self.d_in, self.d_out)
         return WeightGeneratorFn.apply(dims, text_emb, *(self.log_scales[h] for h in HEADS), *self._head_parameters())
 
-    def _log_scale_vector(self) -> torch.Tensor:
-        return torch.cat([self.log_scales[h].detach().reshape(1) for h in HEADS])
+    def _log_scale_vector(self) -> List[torch.Tensor]:
+        """The three 1-element log-scale parameters, read in place by ghf_weightgen_fwd (no concatenation kernel)."""
+        return [self.log_scales[h].detach() for h in HEADS]
 
     def generate(self, text_emb: torch.Tensor, layout: int = _native.WLAYOUT_NATURAL):
         """[R,T] embeddings -> (W_msg | Wfrag, W_self | None, bias) device tensors in `layout`."""

@@ -8,6 +8,7 @@ at 10 M edges, far more than the whole device forward.
 
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -144,11 +145,16 @@ class GraphPlan:
 def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: List[str], N: int, d: int,
                device: torch.device, force_generic: bool = False,
                row_range: Optional[Tuple[int, int]] = None,
-               owner: Optional[Tuple[int, int, int]] = None) -> GraphPlan:
+               owner: Optional[Tuple[int, int, int]] = None,
+               owner_bounds: Optional[Tuple[torch.Tensor, int, int]] = None,
+               edge_range: Optional[Tuple[int, int]] = None) -> GraphPlan:
     """Run K0 on `device`.  Raises IndexError on out-of-range node or relation ids.
 
     Multi-GPU shards keep only the in-edges of the rows they own: `row_range=(lo, hi)` for one contiguous range,
-    or `owner=(S, G, g)` for block-cyclic ownership (row v belongs to rank (v // S) % G)."""
+    `owner=(S, G, g)` for block-cyclic ownership (row v belongs to rank (v // S) % G), or `owner_bounds=(bounds, G, g)`
+    for slots of unequal size (row v lies in slot s: bounds[s] <= v < bounds[s+1]; slot s belongs to rank s % G — shards
+    balanced by in-edge count).  `edge_range=(lo, hi)` keeps the edges with these positions in the caller's list whatever
+    their ends (edge-range shards: the ranks' partial sums are reduced afterwards)."""
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
     E = edge_index.size(1)
@@ -159,8 +165,15 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range
-    if row_range is not None or owner is not None:
-        if owner is not None:
+    if row_range is not None or owner is not None or owner_bounds is not None or edge_range is not None:
+        if edge_range is not None:
+            keep = torch.zeros(ei.size(1), dtype=torch.bool, device=device)
+            keep[edge_range[0]:edge_range[1]] = True
+        elif owner_bounds is not None:
+            bounds, G, g = owner_bounds
+            slot = torch.bucketize(ei[1], bounds.to(device=device, dtype=torch.int64)[1:], right=True)
+            keep = (slot % G) == g
+        elif owner is not None:
             S, G, g = owner
             keep = (torch.div(ei[1], S, rounding_mode="floor") % G) == g
         else:
@@ -199,23 +212,44 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     return plan
 
 
+FULL_FINGERPRINT_MAX = 1 << 17     # lists up to this length are fingerprinted whole
+SAMPLED_POSITIONS = 4096            # longer ones at this many seeded-random positions (plus both ends)
+_SAMPLE_IDX: dict = {}
+
+
 def _texts_fingerprint(edge_texts: Sequence[str]) -> Tuple:
+    """What the plan cache compares of a relation list besides its identity and length.
+
+    The reference maps the strings to ids on every call (models/hypergnn.py:264-268), so a list edited in place must not
+    hit a stale plan.  Up to FULL_FINGERPRINT_MAX entries the whole content is hashed (strings cache their hashes: ~1 ms
+    at 2^17); a longer list is sampled at SAMPLED_POSITIONS positions drawn once per length from a seeded generator — an
+    in-place edit of a 10 M-entry list is caught with the probability that it touches a sampled position or changes
+    the length (a full pass over 10 M Python objects costs several warm forwards; `GHF_PLAN_CACHE=0` disables the
+    cache for callers who edit large lists in place, `clear_plan_cache()` drops it once)."""
     n = len(edge_texts)
     if n == 0:
         return (0,)
-    step = max(1, n // 61)
-    return (n,) + tuple(edge_texts[i] for i in range(0, n, step)) + (edge_texts[-1],)
+    if n <= FULL_FINGERPRINT_MAX:
+        return (n, hash(tuple(edge_texts)))
+    idx = _SAMPLE_IDX.get(n)
+    if idx is None:
+        idx = np.unique(np.concatenate([np.random.default_rng(n).integers(0, n, SAMPLED_POSITIONS), [0, n - 1]])).tolist()
+        if len(_SAMPLE_IDX) >= 16:
+            _SAMPLE_IDX.pop(next(iter(_SAMPLE_IDX)))
+        _SAMPLE_IDX[n] = idx
+    return (n, hash(tuple(edge_texts[i] for i in idx)))
 
 
 class PlanCache:
     """Small LRU of GraphPlans keyed on the identity of the inputs.
 
     Key: edge_index storage pointer, shape, in-place version counter and device;
-    the edge_texts list object identity, its length and a strided sample of its
-    entries; N; d.  The cache keeps references to both inputs so their ids
-    cannot be recycled while an entry lives.  A list mutated in place at
-    positions the sample does not cover is NOT detected: call `clear()` (or
-    pass a new list) after editing relations in place.
+    the edge_texts list object identity and its content fingerprint
+    (`_texts_fingerprint`: the whole list up to 2^17 entries, 4096 seeded-random
+    positions beyond); N; d.  The cache keeps references to both inputs so their
+    ids cannot be recycled while an entry lives.  Writes through
+    `edge_index.data` bypass the version counter and are not seen.
+    `GHF_PLAN_CACHE=0` makes every lookup a miss.
     """
 
     def __init__(self, capacity: int = 4) -> None:
@@ -231,6 +265,9 @@ class PlanCache:
                 id(edge_texts), _texts_fingerprint(edge_texts), N, d, str(device)) + tuple(extra)
 
     def get(self, key: Tuple) -> Optional[GraphPlan]:
+        if os.environ.get("GHF_PLAN_CACHE") == "0":
+            self.misses += 1
+            return None
         ent = self._entries.get(key)
         if ent is None:
             self.misses += 1

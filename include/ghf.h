@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 8
+#define GHF_ABI_VERSION 9
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -97,12 +97,14 @@ int ghf_plan_build(const int64_t* edge_index /* [2,E] row 0 = src, row 1 = dst *
  *  head_params: 3 heads (W_msg, W_self, bias) x (num_hidden+1) Linear layers x {weight,bias},
  *               flattened as head_params[(head*(num_hidden+1) + layer)*2 + {0,1}];
  *               weights are [out,in] row-major as nn.Linear stores them.
+ *  log_scales: host array of three device pointers, one float each (the reference's three 1-element parameters
+ *               log_scales.{W_msg,W_self,bias}, weight_generator.py:85-88, read in place).
  *  hidden_ws:   scratch for hidden activations, >= 3*2*R*max(Hh,T) floats.
  *  layout NATURAL: W_msg,W_self [R,d_in,d_out], bias [R,d_out] (any d_in,d_out).
  *  layout FRAG16:  requires d_in == d_out == d, d % 16 == 0; W_msg is the combined
  *                  fragment buffer of 2*R*d*d floats and W_self must be NULL. */
 int ghf_weightgen_fwd(const float* text_emb /* [R,T] */, const float* const* head_params,
-                      const float* log_scales /* [3] device */, int R, int T, int Hh, int num_hidden,
+                      const float* const* log_scales /* [3] host array of device pointers */, int R, int T, int Hh, int num_hidden,
                       int d_in, int d_out, int layout, float* hidden_ws,
                       float* W_msg, float* W_self, float* bias, void* stream);
 

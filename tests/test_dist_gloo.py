@@ -32,10 +32,17 @@ class OracleOps:
     def message_config(self, d):
         return self.bn, 0, 48, 128
 
-    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner):
-        S, G, g = owner
-        keep = (edge_index[1] // S) % G == g                         # a rank owns the in-edges of its rows
-        return SimpleNamespace(unique_texts=unique, ei=edge_index[:, keep], rel=rel_ids[keep], N=N, wlayout=0)
+    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner=None, owner_bounds=None, edge_range=None):
+        if edge_range is not None:                                   # edge-range shards: a slice of the edge list
+            keep = torch.zeros(edge_index.size(1), dtype=torch.bool)
+            keep[edge_range[0]:edge_range[1]] = True
+        elif owner_bounds is not None:                               # slots of unequal size, slot s -> rank s % G
+            bounds, G, g = owner_bounds
+            keep = (torch.bucketize(edge_index[1], bounds[1:], right=True) % G) == g
+        else:
+            S, G, g = owner
+            keep = (edge_index[1] // S) % G == g                     # a rank owns the in-edges of its rows
+        return SimpleNamespace(unique_texts=unique, ei=edge_index[:, keep], rel=rel_ids[keep], N=N, wlayout=0, E=int(keep.sum()))
 
     @staticmethod
     def _params(model):
@@ -91,13 +98,27 @@ class OracleOps:
             self.split_range(plan, h_out, h_split_out, lo, hi)
 
 
+    # edge-range shards (dist.NativeOps.layer_raw / scale_rows / tail_rows)
+    def layer_raw(self, model, l, w, h, h_split, plan, partial):
+        agg = O.message_passing_factorised(h, plan.ei, plan.rel, w["W_msg"], w["W_self"], w["bias"])
+        cnt = torch.bincount(plan.ei[1], minlength=h.size(0)).to(agg.dtype)
+        partial.copy_(agg * cnt[:, None])                            # the oracle's mean times this shard's in-degree = raw sums
+
+    def scale_rows(self, sums, inv):
+        return sums * inv[:, None]
+
+    def tail_rows(self, model, l, agg, h, h_out, lo, hi):
+        p = self._params(model)
+        h_out[lo:hi] = O.layer_tail(agg[lo:hi], h[lo:hi], p[f"layer_norms.{l}.weight"], p[f"layer_norms.{l}.bias"])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case_name, block_nodes, chunks, split, ret):
+def _worker(rank, world, port, case_name, block_nodes, chunks, split, ret, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -106,7 +127,7 @@ def _worker(rank, world, port, case_name, block_nodes, chunks, split, ret):
         cfg = cases.MODELS[case.model]
         model = HyperGNN(cfg.text_dim, cfg.node_feat_dim, cfg.hidden_dim, cfg.num_layers).eval()
         model.load_state_dict({k: torch.from_numpy(v) for k, v in cfg.params().items()})
-        runner = ShardedHyperGNN(model, ops=OracleOps(block_nodes, split), chunks=chunks)
+        runner = ShardedHyperGNN(model, ops=OracleOps(block_nodes, split), chunks=chunks, **(kw or {}))
         x, ei = torch.from_numpy(case.node_features), torch.from_numpy(case.edge_index)
         out = runner(x, ei, case.edge_texts)
         out2 = runner(x, ei, case.edge_texts)                         # second call reuses the shard plan
@@ -133,6 +154,49 @@ def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn, chun
         assert_close(ret[r], g["out"], f"{case_name} world={world} rank={r}")
     for r in range(1, world):
         assert np.array_equal(ret[r], ret[0]), "all ranks must hold the same gathered result"
+
+
+@pytest.mark.parametrize("world,case_name,bn,chunks,split,kw", [
+    (2, "g3_mid32", 64, 3, False, dict(exchange="pairs")), (3, "g3_mid32", 216, 4, True, dict(exchange="pairs")),
+    (3, "g3_mid32", 64, 3, True, dict(balance="edges")), (2, "g2_toy", 8, 4, False, dict(balance="edges")),
+    (3, "g2_chain", 4, 2, True, dict(balance="edges")),
+    (2, "g3_mid32", 64, 1, False, dict(mode="edges")), (3, "g3_mid32", 216, 1, False, dict(mode="edges")),
+    (3, "g2_toy", 8, 1, False, dict(mode="edges"))])
+def test_sharded_variants_equal_reference(golden_dir, world, case_name, bn, chunks, split, kw):
+    """The pairwise exchange (every rank sends its slot straight to each peer), slots balanced by in-edge count (unequal
+    sizes, pairwise exchange), and the north-star split — edge-range shards, raw partial sums reduced across ranks, tail on
+    the owned rows, all-gather — all reproduce the reference on every rank (g3_mid32 has a 510-in-degree hub)."""
+    g = np.load(os.path.join(golden_dir, f"{case_name}.npz"))
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), case_name, bn, chunks, split, ret, kw), nprocs=world, join=True)
+    assert sorted(ret.keys()) == list(range(world))
+    for r in range(world):
+        assert_close(ret[r], g["out"], f"{case_name} world={world} rank={r} {kw}")
+    for r in range(1, world):
+        assert np.array_equal(ret[r], ret[0]), "all ranks must hold the same gathered result"
+
+
+def test_shard_spec_balanced_by_edges():
+    """Power-law in-degrees: equal-row slots leave one rank with the hub's edges; equal-cost cuts do not."""
+    from graph_hypernetwork_forge_amd import synth
+    N, E, bn, world, chunks = 200_000, 2_000_000, 216, 8, 4
+    ei, _ = synth.make_graph_arrays(N, E, 16, seed=1005, kind="powerlaw")
+    nb = -(-N // bn)
+    be = np.bincount(ei[1] // bn, minlength=nb)
+    per_rank = lambda specs: [sum(int(be[lo // bn: -(-hi // bn)].sum()) for lo, hi in s.owned()) for s in specs]   # noqa: E731
+    rows = per_rank([shard_spec(N, bn, world, r, chunks) for r in range(world)])
+    specs = [shard_spec(N, bn, world, r, chunks, be) for r in range(world)]
+    bal = per_rank(specs)
+    assert sum(rows) == sum(bal) == E
+    # no cut can go below the heaviest block (the hub's); beyond that the ranks are level, which equal-row slots are not
+    assert max(bal) <= max(1.15 * E / world, be.max() * 1.05) and max(bal) < max(rows), (rows, bal, int(be.max()))
+    assert sorted(bal)[-2] < 1.15 * E / world
+    covered = np.zeros(N, dtype=np.int32)
+    for s in specs:
+        assert not s.uniform and s.bounds[0] == 0 and s.bounds[-1] >= N and all(b % bn == 0 for b in s.bounds)
+        for lo, hi in s.owned():
+            covered[lo:hi] += 1
+    assert (covered == 1).all()
 
 
 def test_shard_spec_covers_all_rows_once():

@@ -909,6 +909,62 @@ def test_errors_and_cache():
     assert a.shape == (kg.num_nodes, model.hidden_dim) and torch.isfinite(a).all()
 
 
+def test_relations_edited_in_place_follow_the_reference():
+    """The reference maps the strings to ids on every call (hypergnn.py:264-268): editing one entry of the SAME list object
+    between two forwards must change the result accordingly, not hit the cached plan."""
+    (case,) = cases.graph_cases(only=["g3_mid32"])
+    cfg = cases.MODELS[case.model]
+    params = cfg.params()
+    model = make_model(cfg, params)
+    x, ei = torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV)
+    texts = list(case.edge_texts)
+    with torch.no_grad():
+        a = model(x, ei, texts)
+        i = len(texts) // 2 + 3                                          # (not an end, not a strided position)
+        texts[i] = next(t for t in texts if t != texts[i])               # that edge now carries another relation
+        b = model(x, ei, texts)
+    ref = O.forward(params, case.node_features, case.edge_index, texts, variant="factorised").numpy()
+    assert_close(b.cpu().numpy(), ref, "after the in-place edit")
+    assert not torch.equal(a, b)
+
+
+def test_text_encoder_encode_one():
+    """reference tests/test_hypergnn.py:44-63: encode_one gives [text_dim], equal strings equal rows, '' and non-ASCII work."""
+    cfg = cases.MODELS["small"]
+    enc = make_model(cfg).text_encoder
+    with torch.no_grad():
+        v = enc.encode_one("located_in", DEV)
+        assert v.shape == (cfg.text_dim,) and torch.isfinite(v).all()
+        assert torch.equal(v, enc.encode_one("located_in", DEV)) and not torch.equal(v, enc.encode_one("works_at", DEV))
+        batch = enc(["located_in", "", "caf\u00e9"], DEV)
+        assert torch.equal(batch[0], v) and torch.equal(batch[1], enc.encode_one("", DEV))
+        assert torch.equal(batch[2], enc.encode_one("caf\u00e9", DEV))
+
+
+def test_captured_graph_survives_cache_eviction():
+    """A GraphedForward keeps the plan (and the token matrices) its captured launches point at: running other graphs through
+    the model's small plan cache, and clearing it, must not change what a replay computes."""
+    cfg = cases.MODELS["small"]
+    model = make_model(cfg)
+    kg0 = synth.make_kg(300, 2400, 5, cfg.node_feat_dim, seed=50)
+    x0, ei0, t0 = torch.from_numpy(kg0.node_features).to(DEV), torch.from_numpy(kg0.edge_index).to(DEV), kg0.edge_texts()
+    with torch.no_grad():
+        want = model(x0, ei0, t0).clone()
+    g = model.graphed(x0, ei0, t0)
+    assert torch.equal(g.replay(), want)
+    with torch.no_grad():
+        for s in range(6):                                               # more graphs (and relation sets) than both LRUs hold
+            kg = synth.make_kg(250 + 10 * s, 2000, 9 + s, cfg.node_feat_dim, seed=60 + s)
+            texts = [t + f"_{s}" for t in kg.edge_texts()]
+            model(torch.from_numpy(kg.node_features).to(DEV), torch.from_numpy(kg.edge_index).to(DEV), texts)
+    model.clear_plan_cache()
+    model.text_encoder._tokens.clear()
+    junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]          # whatever was freed gets reused
+    torch.cuda.synchronize()
+    assert torch.equal(g.replay(), want)
+    del junk
+
+
 def test_forward_ids_equals_forward(golden_dir):
     """The pre-tokenised overload (relation ids + one string per relation) gives the forward's result."""
     (case,) = cases.graph_cases(only=["g3_mid32"])

@@ -23,7 +23,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert set(names) == set(_native.SIGNATURES), "include/ghf.h and _native.SIGNATURES disagree"
     for n in names:
         assert hasattr(lib, n), f"libghf_hip.so does not export {n}"
-    assert lib.ghf_abi_version() == _native.ABI_VERSION == 8
+    assert lib.ghf_abi_version() == _native.ABI_VERSION == 9
 
 
 def test_abi_argument_validation_without_a_gpu():
@@ -157,13 +157,33 @@ def test_plan_cache_keys():
     assert k1 != PlanCache.key(ei, texts, 4, 16, dev) and k1 != PlanCache.key(ei, texts, 3, 32, dev)
     ei.add_(0)                                                          # in-place edit bumps the version counter
     assert k1 != PlanCache.key(ei, texts, 3, 16, dev)
-    texts[0] = "c"                                                      # sampled entries are part of the key
+    texts[0] = "c"                                                      # the content is part of the key
     assert PlanCache.key(ei, texts, 3, 16, dev) != PlanCache.key(ei, ["a", "b", "a"], 3, 16, dev)
+    # an in-place edit ANYWHERE in a list of up to 2^17 entries changes the key (the whole list is fingerprinted) ...
+    names = [f"r{i % 7}" for i in range(100_000)]
+    k2 = PlanCache.key(ei, names, 3, 16, dev)
+    names[54_321] = "r_new"
+    assert k2 != PlanCache.key(ei, names, 3, 16, dev)
+    # ... a longer one is sampled at seeded-random positions (and both ends): same positions on every call
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    big = ["x"] * (plan_mod.FULL_FINGERPRINT_MAX + 5)
+    k3 = PlanCache.key(ei, big, 3, 16, dev)
+    assert k3 == PlanCache.key(ei, big, 3, 16, dev)
+    big[plan_mod._SAMPLE_IDX[len(big)][7]] = "y"
+    assert k3 != PlanCache.key(ei, big, 3, 16, dev)
+    big[-1] = "z"
+    assert len(plan_mod._SAMPLE_IDX[len(big)]) <= plan_mod.SAMPLED_POSITIONS + 2
     cache = PlanCache(capacity=2)
     for i in range(3):
         cache.put(("k", i), object(), ei, texts)
     assert len(cache) == 2 and cache.get(("k", 0)) is None and cache.get(("k", 2)) is not None
     assert (cache.hits, cache.misses) == (1, 1)
+    os.environ["GHF_PLAN_CACHE"] = "0"                                  # every lookup a miss
+    try:
+        assert cache.get(("k", 2)) is None
+    finally:
+        del os.environ["GHF_PLAN_CACHE"]
+    assert cache.get(("k", 2)) is not None
 
 
 # ---- synthetic data -------------------------------------------------------------------------------------
