@@ -278,7 +278,8 @@ def main():
         # kernels that gather pre-split rows get them as in the forward (made by the previous layer's tail)
         hs = _native.split_rows(h, plan.wlayout) if plan.wlayout in _native.SPLIT_LAYOUTS else None
         ln = model.layer_norms[0]
-        slots = [(0, N)] if world == 1 else runner._spec.owned()     # this rank's destination rows
+        edge_sharded = world > 1 and runner.mode == "edges"           # this rank's edges reach every row
+        slots = [(0, N)] if world == 1 or edge_sharded else runner._spec.owned()     # this rank's destination rows
         wide = plan.block_nodes == 1 and _native.rs_supported(d)     # relation-stationary layer (csrc/message_rs.hip)
         if wide:
             from graph_hypernetwork_forge_amd.plan import build_rs
@@ -302,7 +303,7 @@ def main():
             a.record(); msg(); b.record()
         torch.cuda.synchronize()
         k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-        share = sum(hi - lo for lo, hi in slots) / N              # this rank's share of the layer (1.0 at N=1)
+        share = plan.E / E if edge_sharded else sum(hi - lo for lo, hi in slots) / N   # this rank's share of the layer (1.0 at N=1)
         flops = layer_flops(N, E, R, d) * share
         byts = layer_bytes(N, E, R, d) * share
         tf = flops / (k_ms * 1e-3) / 1e12

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ghf_weights_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ghf_score_pairs_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
+    "ghf_set_range_flag": (_i32, [_vp]),
 }
 
 
@@ -157,11 +158,48 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
 # thin wrappers (tensors in, tensors out; all work enqueued on the current stream)
 # ---------------------------------------------------------------------------
 
-def message_config(d: int) -> Tuple[int, int, int, int]:
-    """(block_nodes, weight layout, chunk_rows, split_chunks) of the message kernel for hidden size d."""
+# ---- range guard of the two-fp16-piece kernels (include/ghf.h: ghf_set_range_flag) -------------------------------
+RANGE_ROWS, RANGE_WEIGHTS = 1, 2
+_range_flag: Optional[torch.Tensor] = None
+
+
+def range_guard_enabled() -> bool:
+    return os.environ.get("GHF_RANGE_GUARD", "1") != "0"
+
+
+def range_flag(device) -> torch.Tensor:
+    """The int32 device word the cutting kernels OR into (registered once per process)."""
+    global _range_flag
+    if _range_flag is None or _range_flag.device != torch.device(device):
+        _range_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        _check(load().ghf_set_range_flag(_range_flag.data_ptr()), "ghf_set_range_flag")
+    return _range_flag
+
+
+def message_config(d: int, kernel: Optional[str] = None) -> Tuple[int, int, int, int]:
+    """(block_nodes, weight layout, chunk_rows, split_chunks) of the message kernel for hidden size d; `kernel` names one
+    as GHF_KERNEL would ("pp": the exact fp32-MFMA kernel, "generic", ...)."""
     bn, wl, cr, sc = _i32(0), _i32(0), _i32(0), _i32(0)
-    _check(load().ghf_message_config(int(d), C.byref(bn), C.byref(wl), C.byref(cr), C.byref(sc)), "ghf_message_config")
+    with _lock:
+        old = os.environ.get("GHF_KERNEL")
+        try:
+            if kernel is not None:
+                os.environ["GHF_KERNEL"] = kernel
+            _check(load().ghf_message_config(int(d), C.byref(bn), C.byref(wl), C.byref(cr), C.byref(sc)), "ghf_message_config")
+        finally:
+            if kernel is not None:
+                if old is None:
+                    os.environ.pop("GHF_KERNEL", None)
+                else:
+                    os.environ["GHF_KERNEL"] = old
     return bn.value, wl.value, cr.value, sc.value
+
+
+def exact_config(d: int) -> Tuple[int, int, int, int]:
+    """The plan geometry of the exact (fp32 fma chain) kernel for hidden size d: the fp32-MFMA block kernel where one exists
+    (d = 64, 128), else a CSR plan (generic kernel; relation-stationary layer on fp32 MFMAs for wide rows)."""
+    cfg = message_config(d, "pp")
+    return cfg if cfg[1] == WLAYOUT_FRAG16 else (1, WLAYOUT_NATURAL, 0, 0)
 
 
 def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, block_nodes: int, chunk_rows: int = 0,
@@ -340,9 +378,13 @@ def prefer_rs(d: int, R: int) -> bool:
     return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
 
 
+_rs_exact_override = False
+
+
 def rs_exact() -> bool:
-    """GHF_KERNEL=rs32: the wide-row layer's pass 1 on fp32 MFMAs (exact fma chain) instead of two fp16 pieces."""
-    return os.environ.get("GHF_KERNEL") == "rs32"
+    """GHF_KERNEL=rs32 (or the range guard's fallback): the wide-row layer's pass 1 on fp32 MFMAs (exact fma chain) instead
+    of two fp16 pieces."""
+    return _rs_exact_override or os.environ.get("GHF_KERNEL") == "rs32"
 
 
 def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor,

@@ -21,9 +21,19 @@ int set_err(int code, const char* fmt, ...) {
 
 }  // namespace ghf
 
+namespace ghf {
+static std::atomic<int32_t*> g_range_flag{nullptr};
+int32_t* range_flag_ptr() { return g_range_flag.load(std::memory_order_acquire); }
+}  // namespace ghf
+
 using namespace ghf;
 
 extern "C" {
+
+int ghf_set_range_flag(int32_t* device_word) {
+    g_range_flag.store(device_word, std::memory_order_release);
+    return GHF_OK;
+}
 
 int ghf_abi_version(void) { return GHF_ABI_VERSION; }
 

@@ -91,6 +91,18 @@ __device__ __forceinline__ void split2h(float xs, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(xs - (float)hi);
 }
 
+// ---- range guard of the two-fp16-piece form (include/ghf.h: ghf_set_range_flag) -----------------------------------
+// x 2^s = hi + lo keeps 22 bits of every element within 2^-14 of the row's (matrix's) largest; smaller ones lose bits and
+// below 2^-38 of it vanish.  A row / matrix in which at least 1/8 of the NONZERO entries lie that far down is "wide":
+// the kernels that cut rows or weights OR a bit into the registered flag word, and the host routes the forward to the exact
+// fp32 kernels (models/hypergnn.py).  Scaled values: the largest is in [2^13, 2^14), so "that far down" is |x 2^s| < 0.5.
+int32_t* range_flag_ptr();                                 // capi.hip: the registered device word, or nullptr
+// (GHF_RANGE_ROWS, GHF_RANGE_WEIGHTS: include/ghf.h)
+__device__ __forceinline__ int range_tiny(float xs) { const float a = fabsf(xs); return a != 0.f && a < 0.5f; }
+__device__ __forceinline__ void range_raise(int32_t* flag, int bit, int tiny, int nonzero) {
+    if (flag && tiny > 0 && tiny * 8 >= nonzero) atomicOr(flag, bit);
+}
+
 // Sum over a block of NWAVES*64 threads; `red` is >= NWAVES floats of LDS.
 // All threads get the result.  Contains two barriers.
 template <int NWAVES>

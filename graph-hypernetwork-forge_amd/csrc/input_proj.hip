@@ -19,7 +19,8 @@ constexpr int IP_MT = 2;       // m-tiles (16 rows each) per wave
 template <int NT, bool SPLIT>  // n-tiles of 16 output columns: d = 16*NT
 __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t N, int F,
-                                                              float* __restrict__ h0, char* __restrict__ h_split) {
+                                                              float* __restrict__ h0, char* __restrict__ h_split,
+                                                              int32_t* __restrict__ range_flag) {
     constexpr int D = 16 * NT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -103,6 +104,21 @@ __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __res
                     }
                 }
             }
+            if (SPLIT) {                                  // range guard (common.h); all lanes take part in the reduction
+                float tiny = 0.f, nz = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { tiny += (float)range_tiny(v[t] * up); nz += v[t] != 0.f ? 1.f : 0.f; }
+                if (__ballot(tiny != 0.f)) {
+                    for (int i = 0; i < 2; ++i) {
+                        float& z = i ? nz : tiny;
+                        z += dpp_take<0xB1, 0xF>(z);
+                        z += dpp_take<0x4E, 0xF>(z);
+                        z += dpp_take<0x141, 0xF>(z);
+                        z += dpp_take<0x140, 0xF>(z);
+                    }
+                    if (r < N && c16 == 0) range_raise(range_flag, GHF_RANGE_ROWS, (int)tiny, (int)nz);
+                }
+            }
         }
 }
 
@@ -136,8 +152,8 @@ int launch_input_proj(const float* x, const float* W_in, const float* b_in, int6
         switch (d / 16) {
 #define GHF_IP_CASE(NT)                                                                                                 \
     case NT:                                                                                                            \
-        if (fuse) input_proj_mfma_kernel<NT, true><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, (char*)h_split);   \
-        else input_proj_mfma_kernel<NT, false><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, nullptr);             \
+        if (fuse) input_proj_mfma_kernel<NT, true><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, (char*)h_split, range_flag_ptr());   \
+        else input_proj_mfma_kernel<NT, false><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, nullptr, nullptr);           \
         break;
             GHF_IP_CASE(1) GHF_IP_CASE(2) GHF_IP_CASE(3) GHF_IP_CASE(4) GHF_IP_CASE(5) GHF_IP_CASE(6)
             GHF_IP_CASE(7) GHF_IP_CASE(8) GHF_IP_CASE(9) GHF_IP_CASE(10) GHF_IP_CASE(11) GHF_IP_CASE(12)

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     const int32_t* __restrict__ indeg, int R,
     const void* __restrict__ Wsplit, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail) {
+    int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail,
+    int32_t* __restrict__ range_flag) {
     using C = BxCfg<D>;
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, U = C::U, UW = C::UW;
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
@@ -317,6 +318,16 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                         }
                         *(f16x8*)sp = hi8;
                         *(f16x8*)(sp + D) = lo8;
+                    }
+                }
+                if (h_split_out) {                       // range guard (common.h): rows with many entries far below their largest
+                    int tiny = 0, nz = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { tiny += range_tiny(y[c] * up); nz += y[c] != 0.f; }
+                    if (__ballot(tiny != 0)) {           // (rare)
+                        tiny = (int)row_sum((float)tiny);
+                        nz = (int)row_sum((float)nz);
+                        if ((lane & 15) == 0 && live) range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
                     }
                 }
             }
@@ -834,7 +845,7 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     message_bx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
                                                                    a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
                                                                    a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
-                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
+                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr());
     GHF_LAUNCH_CHECK();
     if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
     return GHF_OK;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
     const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off,
     const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
     const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int64_t row_end,
-    float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail) {
+    float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail, int32_t* __restrict__ range_flag) {
     const int64_t blk = blk0 + blockIdx.x;
     const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
     if (i1 - i0 <= 1) return;
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
             const int sh = split2h_shift(wave_absmax(mx));
             const float up = pow2f(sh);
             _Float16* sp = (_Float16*)h_split_out + (size_t)node * 2 * d;
+            int tiny = 0, nz = 0;
 #pragma unroll
             for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
                 const int o = lane + 64 * c;
@@ -215,8 +216,13 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
                     split2h(x[c] * up, hi, lo);
                     sp[o] = hi;
                     sp[d + o] = lo;
+                    tiny += range_tiny(x[c] * up);
+                    nz += x[c] != 0.f;
                 }
             }
+            tiny = (int)wave_sum((float)tiny);
+            nz = (int)wave_sum((float)nz);
+            if (lane == 0) range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
             if (lane == 0) *(float*)((char*)h_split_out + (size_t)N * d * 4 + (size_t)node * 4) = pow2f(-sh);
         }
     }
@@ -227,7 +233,7 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)cdiv(a.rows, a.block_nodes), (unsigned)cdiv(a.block_nodes, COMB_ROWS));
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
                                                    a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, a.h_split_out, a.wlayout,
-                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM));
+                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr());
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     const int32_t* __restrict__ indeg, int R,
     const void* __restrict__ Wsplit, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail, int dbg_arg) {
+    int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail, int dbg_arg,
+    int32_t* __restrict__ range_flag) {
 #ifdef GHF_ABLATE
     const int dbg = dbg_arg;      // 1: gather one hot row, 2: one relation's weights, 4: no main MFMAs, 8: no scatter, 16: no B loads in the stream
 #else
@@ -562,12 +563,20 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
                 for (int c = 0; c < CPL; ++c) h_out[(size_t)(node0 + v) * D + col[c]] = x[rb][c];
                 if (h_split_out) {
                     _Float16* __restrict__ sp = (_Float16*)h_split_out + (size_t)(node0 + v) * (NPL * D);
+                    int tiny = 0, nz = 0;
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) {
                         _Float16 hi, lo;
                         split2h(x[rb][c] * up, hi, lo);
                         sp[col[c]] = hi;
                         sp[D + col[c]] = lo;
+                        tiny += range_tiny(x[rb][c] * up);
+                        nz += x[rb][c] != 0.f;
+                    }
+                    if (__ballot(tiny != 0)) {                          // (rare) some lane of this row holds a tiny entry
+                        tiny = (int)wave_sum((float)tiny);
+                        nz = (int)wave_sum((float)nz);
+                        if (lane == 0) range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
                     }
                 }
             }
@@ -610,7 +619,7 @@ static int launch_hx_for(const MsgArgs& a, hipStream_t stream) {
     message_hx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
                                                                    a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
                                                                    a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
-                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), dbg);
+                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), dbg, range_flag_ptr());
     GHF_LAUNCH_CHECK();
     if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
     return GHF_OK;
@@ -618,7 +627,7 @@ static int launch_hx_for(const MsgArgs& a, hipStream_t stream) {
 
 // ghf_split_rows, SPLIT2H: one wave per row — the row's largest magnitude picks the power of two
 __global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restrict__ h, int64_t N, int64_t row0, int64_t rows,
-                                                           int d, char* __restrict__ out) {
+                                                           int d, char* __restrict__ out, int32_t* __restrict__ range_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= rows) return;
@@ -629,19 +638,26 @@ __global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restri
     const int sh = split2h_shift(wave_absmax(mx));
     const float up = pow2f(sh);
     _Float16* __restrict__ dst = (_Float16*)(out + row * (4 * (int64_t)d));
+    int tiny = 0, nz = 0;
     for (int k = lane; k < d; k += 64) {
         _Float16 hi, lo;
-        split2h(src[k] * up, hi, lo);
+        const float xs = src[k] * up;
+        split2h(xs, hi, lo);
         dst[k] = hi;
         dst[d + k] = lo;
+        tiny += __popcll(__ballot(range_tiny(xs)));
+        nz += __popcll(__ballot(xs != 0.f));
     }
-    if (lane == 0) *(float*)(out + N * (4 * (int64_t)d) + row * 4) = pow2f(-sh);
+    if (lane == 0) {
+        *(float*)(out + N * (4 * (int64_t)d) + row * 4) = pow2f(-sh);
+        range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
+    }
 }
 
 int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream) {
     if (rows <= 0) return GHF_OK;
     GHF_REQUIRE(cdiv(rows, 4) < (1ll << 31), "split_rows: too many rows per launch");
-    split2h_rows_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, stream>>>(h, N, row0, rows, d, (char*)h_split);
+    split2h_rows_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, stream>>>(h, N, row0, rows, d, (char*)h_split, range_flag_ptr());
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

@@ -302,8 +302,11 @@ __global__ __launch_bounds__(256) void rs_wmax_kernel(const float* __restrict__ 
     }
 }
 __global__ __launch_bounds__(256) void rs_wpack_kernel(const float* __restrict__ Wm, const float* __restrict__ Ws, int d,
-                                                       const int* __restrict__ shift, _Float16* __restrict__ out) {
+                                                       const int* __restrict__ shift, _Float16* __restrict__ out,
+                                                       int32_t* __restrict__ range_flag) {
     __shared__ float tile[32][33];
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     const int r = blockIdx.z >> 1, half = blockIdx.z & 1;
     const float* __restrict__ W = (half ? Ws : Wm) + (size_t)r * d * d;             // natural [k][n]
     const float up = pow2f(shift[r]);
@@ -314,10 +317,15 @@ __global__ __launch_bounds__(256) void rs_wpack_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < 1024; i += 256) {
         const int n = nn0 + (i >> 5), k = k0 + (i & 31);
         _Float16 hi, lo;
-        split2h(tile[i & 31][i >> 5] * up, hi, lo);
+        const float xs = tile[i & 31][i >> 5] * up;
+        split2h(xs, hi, lo);
         base[(size_t)n * d + k] = hi;
         base[(size_t)d * d + (size_t)n * d + k] = lo;
+        if (range_tiny(xs)) atomicAdd(&cnt[0], 1);       // range guard (common.h), per 32 x 32 tile of the relation's matrices
+        if (xs != 0.f) atomicAdd(&cnt[1], 1);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) range_raise(range_flag, GHF_RANGE_WEIGHTS, cnt[0], cnt[1]);
 }
 
 constexpr int RS_MAX_D = 1024, RS_PER_LANE = RS_MAX_D / 64;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(256) void segment_tail_kernel(
     const float* __restrict__ Y, const int64_t* __restrict__ off, const int32_t* __restrict__ hub_of,
     const int64_t* __restrict__ hub_tab, const float* __restrict__ P, const float* __restrict__ h, const float* __restrict__ g,
     const float* __restrict__ b, float eps, int64_t row0, int64_t row_end, float* __restrict__ h_out,
-    char* __restrict__ h_split_out, int64_t n_split, int no_tail) {
+    char* __restrict__ h_split_out, int64_t n_split, int no_tail, int32_t* __restrict__ range_flag) {
     constexpr int d = 64 * CPL;
     const int lane = threadIdx.x & 63;
     const int64_t v = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -420,14 +428,22 @@ __global__ __launch_bounds__(256) void segment_tail_kernel(
         const int sh = split2h_shift(wave_absmax(mx));
         const float up = pow2f(sh);
         _Float16* __restrict__ sp = (_Float16*)(h_split_out + (size_t)v * 4 * d);
+        int tiny = 0, nz = 0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             _Float16 hi, lo;
             split2h(x[c] * up, hi, lo);
             sp[lane + 64 * c] = hi;
             sp[d + lane + 64 * c] = lo;
+            tiny += range_tiny(x[c] * up);
+            nz += x[c] != 0.f;
         }
         if (lane == 0) *(float*)(h_split_out + (size_t)n_split * 4 * d + (size_t)v * 4) = pow2f(-sh);
+        if (__ballot(tiny != 0)) {                         // range guard (common.h)
+            tiny = (int)wave_sum((float)tiny);
+            nz = (int)wave_sum((float)nz);
+            if (lane == 0) range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
+        }
     }
 }
 
@@ -452,7 +468,7 @@ int launch_weights_pack_rs(const float* Wm, const float* Ws, int R, int d, void*
     float* inv = (float*)((char*)out + (size_t)R * 8 * d * d);
     rs_wmax_kernel<<<R, 256, 0, stream>>>(Wm, Ws, d, inv, shift_ws);
     GHF_LAUNCH_CHECK();
-    rs_wpack_kernel<<<dim3(d / 32, d / 32, 2 * R), 256, 0, stream>>>(Wm, Ws, d, shift_ws, (_Float16*)out);
+    rs_wpack_kernel<<<dim3(d / 32, d / 32, 2 * R), 256, 0, stream>>>(Wm, Ws, d, shift_ws, (_Float16*)out, range_flag_ptr());
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
@@ -505,7 +521,7 @@ int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_o
 #define GHF_RS_CASE(CPL)                                                                                                        \
     case CPL:                                                                                                                   \
         segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out,    \
-                                                           (char*)h_split_out, n_split, nt);                                    \
+                                                           (char*)h_split_out, n_split, nt, range_flag_ptr());                 \
         break;
         GHF_RS_CASE(2) GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)
 #undef GHF_RS_CASE

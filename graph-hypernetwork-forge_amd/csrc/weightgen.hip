@@ -224,9 +224,12 @@ __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restric
 // relation pulls its matrix into LDS, finds the largest magnitude, and rewrites the same bytes as fp16 B fragments
 //   Wh[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8],  piece 0 = fp16(w 2^s), piece 1 = fp16(w 2^s - piece 0)
 // (4 bytes per weight either way: in place); scales[r] = 2^-s.
-__global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, float* __restrict__ scales, int d) {
+__global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, float* __restrict__ scales, int d,
+                                                         int32_t* __restrict__ range_flag) {
     extern __shared__ float wbuf[];                      // [2d][d]
     __shared__ float red[16];
+    __shared__ int cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     const int r = blockIdx.x, tid = threadIdx.x, n = 2 * d * d;
     float* __restrict__ mine = W + (size_t)r * n;
     float mx = 0.f;
@@ -251,12 +254,22 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
         const int ks = fk % NKS, ct = fk / NKS;
         const int o = ct * 16 + (slot & 15), kk0 = ks * 32 + (slot >> 4) * 8;
         _Float16 hi[8], lo[8];
+        int tiny = 0, nz = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split2h(wbuf[(kk0 + e) * d + o] * up, hi[e], lo[e]);
+        for (int e = 0; e < 8; ++e) {
+            const float xs = wbuf[(kk0 + e) * d + o] * up;
+            split2h(xs, hi[e], lo[e]);
+            tiny += range_tiny(xs);
+            nz += xs != 0.f;
+        }
         _Float16* p = dst + ((size_t)fk * 2 * 64 + slot) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { p[e] = hi[e]; p[512 + e] = lo[e]; }
+        if (tiny) atomicAdd(&cnt[0], tiny);              // range guard (common.h): this relation's matrix as a whole
+        if (nz) atomicAdd(&cnt[1], nz);
     }
+    __syncthreads();
+    if (tid == 0) range_raise(range_flag, GHF_RANGE_WEIGHTS, cnt[0], cnt[1]);
 }
 
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
@@ -322,7 +335,7 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
     GHF_LAUNCH_CHECK();
     const size_t lds = (size_t)2 * d * d * 4;
     GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
-    wg_pack2h_kernel<<<R, 1024, lds, stream>>>(out, out + (size_t)R * 2 * d * d, d);
+    wg_pack2h_kernel<<<R, 1024, lds, stream>>>(out, out + (size_t)R * 2 * d * d, d, range_flag_ptr());
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
@@ -396,7 +409,7 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
     if (layout == GHF_WLAYOUT_SPLIT2H) {
         const size_t lds = (size_t)2 * n_mat * 4;
         GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
-        wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out);
+        wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out, range_flag_ptr());
         GHF_LAUNCH_CHECK();
     }
     return GHF_OK;

@@ -383,10 +383,27 @@ class ShardedHyperGNN:
         h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
         h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
+        guard = isinstance(self.ops, NativeOps) and model._guarded(plan) and self.profile == "full"
+        if guard:
+            flag = _native.range_flag(device)
+            flag.zero_()
         if self.mode == "edges":
-            return self._forward_edges(node_features, plan, spec, text_embs, h, h_next)
-        if self.ops.exchanges_split(plan):
-            return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
+            out = self._forward_edges(node_features, plan, spec, text_embs, h, h_next)
+        elif self.ops.exchanges_split(plan):
+            out = self._forward_split(node_features, plan, spec, text_embs, h, h_next)
+        else:
+            out = self._forward_rows(node_features, plan, spec, text_embs, h, h_next)
+        if guard:
+            # every rank must take the same decision: the flags are OR-ed across the ranks (one 4-byte collective)
+            bits = flag.cpu() if self.backend == "gloo" else flag
+            dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+            if int(bits.item()):
+                raise RuntimeError("ShardedHyperGNN: the range guard of the two-fp16-piece kernels fired (include/ghf.h: "
+                                   "ghf_set_range_flag); run the sharded forward with GHF_KERNEL=pp (exact kernels)")
+        return out
+
+    def _forward_rows(self, node_features, plan, spec, text_embs, h, h_next) -> torch.Tensor:
+        model, N, device = self.model, node_features.size(0), node_features.device
         all_w, ready = self.ops.all_weights(model, text_embs, plan)
         self.ops.input_proj(model, node_features, h[:N], None, plan)
         for l in range(model.num_layers):

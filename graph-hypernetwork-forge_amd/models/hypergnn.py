@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native
-from ..plan import GraphPlan, PlanCache, build_plan, build_rs, relation_ids
+from ..plan import GraphPlan, PlanCache, build_plan, build_rs, exact_plan, relation_ids
 from .weight_generator import WeightGenerator, require_inference, wants_grad
 
 
@@ -113,7 +113,15 @@ class GraphedForward:
             if node_features.shape != self.input.shape:
                 raise ValueError(f"captured for features {tuple(self.input.shape)}, got {tuple(node_features.shape)}")
             self.input.copy_(node_features)
+        model, plan = self._keep[0], self._keep[1]
+        guard = model._guarded(plan)
+        if guard:
+            flag = _native.range_flag(self.input.device)
+            flag.zero_()
         self.graph.replay()
+        if guard and int(flag.item()):                      # (one 4-byte read per replay; GHF_RANGE_GUARD=0 skips it)
+            with torch.no_grad():
+                self.output.copy_(model._forward_exact(self.input, plan, int(flag.item())))
         return self.output
 
     __call__ = replay
@@ -140,6 +148,7 @@ class HyperGNN(nn.Module):
         self.layer_norms = nn.ModuleList([nn.LayerNorm(hidden_dim) for _ in range(num_layers)])
         self._plans = PlanCache()
         self._wg_stream = None
+        self.last_range_flags = 0        # what the range guard saw in the last forward (include/ghf.h: ghf_set_range_flag)
 
     # -- plan ------------------------------------------------------------------------------
     def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], num_nodes: int,
@@ -212,6 +221,25 @@ class HyperGNN(nn.Module):
             return self._forward_recorded(node_features, plan, edge_index)
         return self.forward_planned(node_features, plan)
 
+    # -- range guard of the two-fp16-piece kernels (include/ghf.h: ghf_set_range_flag) ---------------------------
+    def _guarded(self, plan: GraphPlan) -> bool:
+        pieces = plan.wlayout in _native.SPLIT_LAYOUTS or (plan.block_nodes == 1 and _native.rs_supported(self.hidden_dim)
+                                                          and not _native.rs_exact())
+        return pieces and _native.range_guard_enabled()
+
+    def _forward_exact(self, x: torch.Tensor, plan: GraphPlan, flags: int) -> torch.Tensor:
+        """The forward again on the exact fp32 kernels: some row of h (flags & 1) or some relation's generated weights
+        (flags & 2) spans more dynamic range than two fp16 pieces hold (the reference computes in plain fp32,
+        hypergnn.py:202,228)."""
+        self.last_range_flags = flags
+        ep = exact_plan(plan, self.hidden_dim)
+        old = _native._rs_exact_override
+        _native._rs_exact_override = True
+        try:
+            return self.forward_planned(x, ep, guard=False)
+        finally:
+            _native._rs_exact_override = old
+
     def _check_dropout(self) -> None:
         if self.training and self.dropout > 0.0:
             raise NotImplementedError("HyperGNN: dropout in training mode is not implemented on the HIP path")
@@ -224,11 +252,20 @@ class HyperGNN(nn.Module):
         device = node_features.device
         if plan.train is None:
             plan.train = build_train_plan(edge_index, plan.rel_ids, plan, self.hidden_dim, device)
+        guard = self._guarded(plan)
+        if guard:
+            flag = _native.range_flag(device)
+            flag.zero_()
         text_embs = self.text_encoder(plan.unique_texts, device)
         h = InputProjFn.apply(node_features, self.input_proj.weight, self.input_proj.bias)
         for gen, norm in zip(self.weight_generators, self.layer_norms):
             W_msg, W_self, bias = gen.generate_with_grad(text_embs)
             h = MessageLayerFn.apply(h, W_msg, W_self, bias, norm.weight, norm.bias, norm.eps, plan.train)
+        if guard and int(flag.item()):
+            self.last_range_flags = int(flag.item())
+            raise RuntimeError("HyperGNN (training forward): a row of h or a relation's generated weights spans more dynamic range "
+                               "than the two-fp16-piece kernels hold (include/ghf.h: ghf_set_range_flag); train with "
+                               "GHF_KERNEL=pp (exact fp32 MFMA kernels) or normalise the node features")
         return h
 
     def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True, after=None):
@@ -265,12 +302,29 @@ class HyperGNN(nn.Module):
         return weights, ready
 
     def forward_planned(self, node_features: torch.Tensor, plan: GraphPlan,
-                        exchange=None) -> torch.Tensor:
+                        exchange=None, guard: bool = True) -> torch.Tensor:
         """Forward with an explicit plan.  `exchange(h)` (multi-GPU) runs after every layer to
-        make all rows of h visible on this rank; the plan's row range says which rows it computes."""
+        make all rows of h visible on this rank; the plan's row range says which rows it computes.
+        Range guard: the kernels that cut rows / weights into two fp16 pieces flag inputs whose dynamic range those do not
+        hold; the forward then ends with one 4-byte read of that flag (the only host sync of a warm forward;
+        GHF_RANGE_GUARD=0 removes it) and, if it is set, runs again on the exact fp32 kernels."""
         require_inference(self, node_features, what=".forward_planned")
         device = node_features.device
         x = node_features if node_features.dtype == torch.float32 else node_features.float()
+        guard = guard and exchange is None and self._guarded(plan) and not torch.cuda.is_current_stream_capturing()
+        if guard:
+            flag = _native.range_flag(device)
+            flag.zero_()
+        out = self._forward_planned(x, plan, exchange)
+        if guard:
+            bits = int(flag.item())
+            self.last_range_flags = bits
+            if bits:
+                return self._forward_exact(x, plan, bits)
+        return out
+
+    def _forward_planned(self, x: torch.Tensor, plan: GraphPlan, exchange=None) -> torch.Tensor:
+        device = x.device
         if plan.block_nodes == 1 and _native.rs_supported(self.hidden_dim):
             return self._forward_wide(x, plan, exchange)
         text_embs = self.text_encoder(plan.unique_texts, device)     # [U, text_dim]

@@ -62,6 +62,15 @@ RS_HUB_ROWS = 4096           # a destination with more rows than this is summed 
 SRC_MASK = 0x0FFFFFFF
 
 
+def exact_plan(plan: "GraphPlan", d: int) -> "GraphPlan":
+    """`plan`'s edges planned for the exact kernels (built once, kept on the plan)."""
+    if plan.exact is None:
+        src, dst, rel = plan.edge_arrays()
+        plan.exact = build_plan(torch.stack([src, dst]), rel, plan.unique_texts, plan.N, d, plan.sorted_key.device, exact=True)
+        plan.exact.row_lo, plan.exact.row_hi = plan.row_lo, plan.row_hi
+    return plan.exact
+
+
 def build_rs(plan: "GraphPlan") -> RsPlan:
     """From a CSR plan (block_nodes == 1: edges sorted by key = dst * R + relation): the same edges grouped by relation.
     One device sort and one host sync per plan."""
@@ -125,6 +134,17 @@ class GraphPlan:
     row_hi: int = 0
     train: Optional[object] = None  # autograd.TrainPlan, built by the first forward that records gradients
     rs: Optional[RsPlan] = None     # relation-stationary extras, built by the first wide-row forward
+    exact: Optional["GraphPlan"] = None   # the same edges planned for the exact fp32 kernels (range guard fallback)
+
+    def edge_arrays(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(src, dst, relation id) int64 [E] of this plan's edges, decoded from the sorted arrays."""
+        key = self.sorted_key[: self.E].to(torch.int64) & 0xFFFFFFFF
+        raw = self.sorted_src[: self.E].to(torch.int64)
+        if self.block_nodes == 1:
+            return raw & 0xFFFFFFFF, torch.div(key, self.R, rounding_mode="floor"), key % self.R
+        bn = self.block_nodes
+        blk, rem = torch.div(key, self.R * bn, rounding_mode="floor"), key % (self.R * bn)
+        return raw & SRC_MASK, blk * bn + rem % bn, torch.div(rem, bn, rounding_mode="floor")
 
     def bytes(self) -> int:
         ts = (self.rel_ids, self.sorted_key, self.sorted_src, self.seg_off, self.indeg, self.chunk_tab, self.blk_chunk_off,
@@ -147,7 +167,7 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
                row_range: Optional[Tuple[int, int]] = None,
                owner: Optional[Tuple[int, int, int]] = None,
                owner_bounds: Optional[Tuple[torch.Tensor, int, int]] = None,
-               edge_range: Optional[Tuple[int, int]] = None) -> GraphPlan:
+               edge_range: Optional[Tuple[int, int]] = None, exact: bool = False) -> GraphPlan:
     """Run K0 on `device`.  Raises IndexError on out-of-range node or relation ids.
 
     Multi-GPU shards keep only the in-edges of the rows they own: `row_range=(lo, hi)` for one contiguous range,
@@ -161,7 +181,10 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     if E == 0:
         raise ValueError("edge_index has no edges; the reference cannot encode an empty relation list either")
     R = len(unique_texts)
-    bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else _native.message_config(d)
+    if exact:                                     # the exact fp32 kernels (range guard fallback: _native.exact_config)
+        bn, wl, cr, sc = _native.exact_config(d)
+    else:
+        bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else _native.message_config(d)
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range

@@ -162,6 +162,22 @@ int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows,
 /* Bytes of the W_msg buffer ghf_weightgen_fwd fills in `wlayout` (NATURAL: one of the two [R,d_in,d_out] matrices). */
 size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout);
 
+/* ---- range guard of the two-fp16-piece forms ------------------------------------------------------------------------
+ * GHF_WLAYOUT_SPLIT2H rows and weights keep 22 significand bits of every element within 2^-14 of the largest magnitude of
+ * their row (activations) or of their relation's [2d, d] matrix (weights); an element further down loses one bit per
+ * factor of two and vanishes below 2^-38 of the largest.  Bound on a product sum_k x_k w_k: 3 * 2^-22 * sum |x_k w_k|
+ * (the order of the fp32 fma chain it replaces) + 2^-37 * max|x| * sum_k |w_k| over the far-down x_k (and the same with x
+ * and w exchanged).  The second term is invisible unless the large entries meet (near-)zero partners, e.g. one feature
+ * 2^30 above the rest whose weight column is 0 — the reference's fp32 bmm (hypergnn.py:202,228) has no such case.
+ * Every kernel that cuts rows or weights therefore counts, per row / per relation matrix (per 32 x 32 tile in
+ * ghf_weights_pack_rs), the nonzero entries more than 2^14 below the largest; when they are at least 1/8 of the nonzero
+ * entries it ORs GHF_RANGE_ROWS / GHF_RANGE_WEIGHTS into the int32 device word registered here (NULL: no guard).  The
+ * word belongs to the caller, who clears it before a forward and reads it after (the host mirror then repeats the forward
+ * on the exact fp32 kernels).  One word per process (one process drives one GPU). */
+#define GHF_RANGE_ROWS 1
+#define GHF_RANGE_WEIGHTS 2
+int ghf_set_range_flag(int32_t* device_word);
+
 /* ---- K3 alone -------------------------------------------------------------------------
  * Replaces models/hypergnn.py:288-296 on rows [row0,row0+rows): agg already holds
  * out_v (GHF_FLAG_NO_TAIL output, e.g. after a cross-GPU reduction). */

@@ -965,6 +965,63 @@ def test_captured_graph_survives_cache_eviction():
     del junk
 
 
+def _adversarial_model(d, F, rows_outlier=True):
+    """A model whose first-layer input rows (or whose generated weights) carry one entry 2^30 above the rest, aimed at a
+    zero partner: the case the two-fp16-piece kernels cannot hold and the fp32 reference can."""
+    cfg = cases.ModelCfg(text_dim=16, node_feat_dim=F, hidden_dim=d, num_layers=2, seed=909, log_scale=0.0, randomize_ln=True)
+    p = cfg.params()
+    p["input_proj.weight"] = np.eye(d, F, dtype=np.float32)            # h0 = relu(x)
+    p["input_proj.bias"] = np.zeros(d, np.float32)
+    for l in range(cfg.num_layers):
+        for head in ("W_msg", "W_self"):
+            k = max(int(n.split(".")[4]) for n in p if n.startswith(f"weight_generators.{l}.generators.{head}."))
+            W, b = p[f"weight_generators.{l}.generators.{head}.{k}.weight"], p[f"weight_generators.{l}.generators.{head}.{k}.bias"]
+            if rows_outlier:
+                if l == 0:                                              # input column 0 meets zero weights: rows [0, d) of the flat [d*d]
+                    W[:d] = 0.0
+                    b[:d] = 0.0
+            elif l == 0 and head == "W_msg":
+                b[5 * d + 7] = 2.0 ** 20                                # one weight (i = 5, o = 7) 2^20+ above the rest of its matrix
+    return cfg, p
+
+
+@pytest.mark.parametrize("d,what", [(128, "rows"), (128, "weights"), (256, "rows")])
+def test_range_guard_routes_wide_inputs_to_the_exact_kernels(d, what, monkeypatch):
+    """One feature 2^30 above the rest of its row whose weight rows are zero (rows), or one generated weight 2^20 above the
+    rest of its matrix that only ever meets zeros (weights): two fp16 pieces lose the small entries, the reference's fp32
+    bmm (hypergnn.py:202,228) does not.  The cutting kernels flag it, the forward repeats on the exact kernels and matches
+    the oracle; with the guard off the result is visibly wrong (the test is not vacuous)."""
+    F, N, E, R = d, 600, 5000, 5
+    cfg, params = _adversarial_model(d, F, rows_outlier=what == "rows")
+    kg = synth.make_kg(N, E, R, F, seed=31)
+    x = np.abs(kg.node_features).astype(np.float32) + 0.1
+    if what == "rows":
+        x[::3, 0] *= 2.0 ** 30                                           # a third of the rows: column 0 dwarfs the rest
+    else:
+        x[:, 5] = -1.0                                                   # relu -> exactly 0: the huge weight's input column
+    ei, texts = kg.edge_index, kg.edge_texts()
+    ref = O.forward(params, x, ei, texts, variant="factorised").numpy()
+    model = make_model(cfg, params)
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), texts)
+    assert model.last_range_flags & (_native.RANGE_ROWS if what == "rows" else _native.RANGE_WEIGHTS)
+    assert_close(out.cpu().numpy(), ref, f"guarded forward d={d} {what}")
+    g = model.graphed(torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), texts)      # the captured forward is guarded too
+    assert_close(g.replay().cpu().numpy(), ref, f"guarded replay d={d} {what}")
+    monkeypatch.setenv("GHF_RANGE_GUARD", "0")
+    model2 = make_model(cfg, params)
+    with torch.no_grad():
+        raw = model2(torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), texts)
+    with pytest.raises(AssertionError):
+        assert_close(raw.cpu().numpy(), ref, "unguarded")
+    monkeypatch.delenv("GHF_RANGE_GUARD")
+    # well-scaled inputs never trip it
+    model3 = make_model(cfg, cfg.params())
+    with torch.no_grad():
+        model3(torch.from_numpy(kg.node_features).to(DEV), torch.from_numpy(ei).to(DEV), texts)
+    assert model3.last_range_flags == 0
+
+
 def test_forward_ids_equals_forward(golden_dir):
     """The pre-tokenised overload (relation ids + one string per relation) gives the forward's result."""
     (case,) = cases.graph_cases(only=["g3_mid32"])
