@@ -311,15 +311,20 @@ def main():
         # HBM-side traffic per launch from the committed rocprofv3 PMC passes of this same command (separate
         # --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read)
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_message_kernel_pmc.json")
+        pmc_name = {"c3": "r02_message_kernel_pmc.json", "c2": "r02_c2_kernel_pmc.json", "c5": "r02_c5_kernel_pmc.json"}[args.workload]
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         pmc = {}
-        if args.workload == "c3" and world == 1 and os.path.exists(pmc_path):
+        if world == 1 and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if kern_name(plan, d) not in pmc.get("_kernel", ""):
-                pmc = {}
+            names = [pmc.get("_kernel", "")] if "kernels" not in pmc else list(pmc["kernels"])
+            want = ["edge_transform", "segment_tail"] if (plan.block_nodes == 1 and _native.rs_supported(d)) else [kern_name(plan, d)]
+            if not all(any(w_ in n for n in names) for w_ in want):
+                pmc = {}                                    # counters of another kernel: not this run's traffic
         if pmc:
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-            traffic_src = "profiles/r01_message_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2)"
+            parts = [pmc] if "kernels" not in pmc else [v for k, v in pmc["kernels"].items() if "edge_transform" in k or "segment_tail" in k]
+            traffic = sum((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for v in parts)
+            traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2; per-launch means" + \
+                          (", summed over the layer's kernels)" if len(parts) > 1 else ")")
         kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<128>", _native.WLAYOUT_SPLIT3: "message_sx_kernel<128>"}.get(
             plan.wlayout, "message_pp_kernel<%d>" % d if plan.block_nodes > 1 else "message_generic_kernel")
         if wide:
@@ -330,7 +335,7 @@ def main():
         if wide and not _native.rs_exact():
             prod, mpeak = 3, F16_MATRIX_PEAK_TF
         l2_bytes = None
-        if traffic is not None and "TCC_REQ_sum" in pmc:
+        if traffic is not None and "TCC_REQ_sum" in pmc:      # (single-kernel layers)
             l2_bytes = pmc["TCC_REQ_sum"] * 128.0
         roofline = {"kernel": kern,
                     "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

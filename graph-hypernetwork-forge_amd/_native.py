@@ -180,12 +180,13 @@ def message_config(d: int, kernel: Optional[str] = None) -> Tuple[int, int, int,
     """(block_nodes, weight layout, chunk_rows, split_chunks) of the message kernel for hidden size d; `kernel` names one
     as GHF_KERNEL would ("pp": the exact fp32-MFMA kernel, "generic", ...)."""
     bn, wl, cr, sc = _i32(0), _i32(0), _i32(0), _i32(0)
+    lib = load()                                    # (before taking the lock: load() takes it too)
     with _lock:
         old = os.environ.get("GHF_KERNEL")
         try:
             if kernel is not None:
                 os.environ["GHF_KERNEL"] = kernel
-            _check(load().ghf_message_config(int(d), C.byref(bn), C.byref(wl), C.byref(cr), C.byref(sc)), "ghf_message_config")
+            _check(lib.ghf_message_config(int(d), C.byref(bn), C.byref(wl), C.byref(cr), C.byref(sc)), "ghf_message_config")
         finally:
             if kernel is not None:
                 if old is None:

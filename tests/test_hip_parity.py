@@ -1097,6 +1097,62 @@ def test_full_size_c3_layer_properties(kernel):
     assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), "sampled rows of the 10M-edge layer")
 
 
+def test_full_size_c5_shard_properties():
+    """One GPU's share of BASELINE config 5 (power-law KG, 4 M rows resident, 8 M in-edges owned, 256 relations, hidden 256)
+    through the relation-stationary layer — with the graph's real hubs (in-degrees far above plan.RS_HUB_ROWS, no patched
+    threshold): bitwise reproducible, LayerNorm moments, isolated rows, and sampled rows INCLUDING the hubs against a
+    float64 evaluation of their in-edge subgraph (reference statement: models/hypergnn.py:201-230, 288-296)."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    N, E, R, d = 4_000_000, 8_000_000, 256, 256
+    ei, rel = synth.make_graph_arrays(N, E, R, seed=1005, kind="powerlaw")
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    assert plan.block_nodes == 1 and plan.E == E and _native.rs_supported(d)
+    rs = plan_mod.build_rs(plan)
+    deg = np.bincount(ei[1], minlength=N)
+    hubs = np.argsort(deg)[-3:]
+    assert rs.hub_of is not None and deg[hubs].min() > 4 * plan_mod.RS_HUB_ROWS, "this shard must hold real hubs"
+    g = torch.Generator(device="cpu").manual_seed(2)
+    h = torch.randn(N, d, generator=g)
+    Wm, Ws = synth.normal(12, "Wm", (R, d, d), std=0.05), synth.normal(12, "Ws", (R, d, d), std=0.05)
+    b = synth.normal(12, "b", (R, d), std=0.3)
+    gamma, beta = np.ones(d, np.float32), np.zeros(d, np.float32)
+    h_d, Wm_d, Ws_d, b_d = h.to(DEV), t(Wm), t(Ws), t(b)
+    Y = rs.scratch(E, d, DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.empty_like(h_d)
+        _native.edge_transform_fwd(h_d, rs, Wm_d, Ws_d, b_d, Y)
+        _native.segment_tail_fwd(Y, rs, h_d, t(gamma), t(beta), 1e-5, out)
+        outs.append(out)
+    torch.cuda.synchronize()
+    out1 = outs[0]
+    assert torch.equal(out1, outs[1]), "the relation-stationary layer must be bitwise reproducible"
+    assert torch.isfinite(out1).all()
+    assert out1.mean(dim=1).abs().max().item() < 1e-4
+    assert (out1.var(dim=1, unbiased=False) - 1).abs().max().item() < 1e-2
+    iso = (plan.indeg == 0).nonzero().flatten()[:4096]
+    assert iso.numel() > 0
+    want = torch.nn.functional.layer_norm(torch.relu(h_d[iso]), (d,), t(gamma), t(beta), 1e-5)
+    assert_close(out1[iso].cpu().numpy(), want.cpu().numpy(), "isolated rows")
+    # sampled destinations + the three largest hubs, in float64 on their in-edge subgraph
+    rows = np.unique(np.concatenate([synth.randint(6, "rows", 200, N), hubs]))
+    keep = np.isin(ei[1], rows)
+    s_src, s_dst, s_rel = (torch.from_numpy(a[keep]) for a in (ei[0], ei[1], rel))
+    pos = torch.full((N,), -1, dtype=torch.int64)
+    pos[torch.from_numpy(rows)] = torch.arange(len(rows))
+    acc = torch.zeros(len(rows), d, dtype=torch.float64)
+    for r in torch.unique(s_rel).tolist():
+        e = (s_rel == r).nonzero().flatten()
+        c = (h[s_src[e]].double() @ torch.from_numpy(Wm[r]).double() + torch.from_numpy(b[r]).double()
+             + h[s_dst[e]].double() @ torch.from_numpy(Ws[r]).double())
+        acc.index_add_(0, pos[s_dst[e]], c)
+    cnt = torch.from_numpy(np.maximum(deg[rows], 1)).double()[:, None]
+    x = torch.relu(acc / cnt + h[torch.from_numpy(rows)].double())
+    ref = torch.nn.functional.layer_norm(x, (d,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5)
+    assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), f"sampled rows and hubs (in-degrees {deg[hubs].tolist()}) of the C5 shard")
+
+
 # ---- the multi-GPU driver on one GPU: NCCL world of 1, 4 overlapped chunks ------------------------------
 
 def _two_rank_worker(rank, world, port, name, ret):

@@ -60,6 +60,18 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.ghf_tail_fwd(None, None, None, None, 1e-5, 0, 1, 8, None, None) == -1
 
 
+def test_message_config_is_safe_as_the_first_call_of_a_process():
+    """message_config takes the module lock to name a kernel; loading the library takes it too (a fresh process whose first
+    native call is a plan build must not deadlock)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from graph_hypernetwork_forge_amd import _native; "
+            "print(_native.message_config(128)[0], _native.exact_config(128)[0], _native.exact_config(20)[0])" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["384", "216", "1"], out.stderr[-500:]
+
+
 def test_header_has_no_torch_or_cxx_types():
     with open(os.path.join(_build.INCLUDE, "ghf.h")) as f:
         text = f.read()

@@ -1,33 +1,45 @@
 #!/bin/bash
-# Collect PMC counters of the message kernel with rocprofv3, one pass per counter group (run on the GPU box):
-#   tools/pmc.sh <out-prefix>        -> gpurun_out/<out-prefix>_{tcc,fetch,write,sq}.csv + <out-prefix>_pmc.json (per-launch means)
-# Counters only (--pmc): never combined with the trace domains on this pool.
+# Collect PMC counters of one kernel with rocprofv3, one pass per counter group (run on the GPU box):
+#   tools/pmc.sh <out-prefix> <kernel-name-regex> -- <program> [args...]
+#     -> gpurun_out/<out-prefix>_{tcc,fetch,write,sq}.csv + <out-prefix>_pmc.json (per-launch means of the matching kernel)
+#   default program: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5, kernel message_(bx|hx|sx|pp|mfma)_kernel
+# Counters only (--pmc): never combined with the trace domains on this pool.  FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts
+# a wide streaming read at half its bytes (MI355X_MICROARCH.md): readers double FETCH_SIZE.
 set -e
 cd "$(dirname "$0")/.."
-out=${1:-pmc}
+out=${1:-pmc}; kern=${2:-'message_(bx|hx|sx|pp|mfma)_kernel'}
+if [ "$3" = "--" ]; then shift 3; else set -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5; fi
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 run() {  # name, counters...
   name=$1; shift
   rm -rf gpurun_out/_pmc_$name
-  rocprofv3 --pmc "$@" -d gpurun_out/_pmc_$name -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5 > gpurun_out/_pmc_$name.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc "$@" -d gpurun_out/_pmc_$name -o p --output-format csv -- "${CMD[@]}" > gpurun_out/_pmc_$name.log 2>&1
   f=$(find gpurun_out/_pmc_$name -name '*counter_collection.csv' | head -1)
-  grep -E 'Counter_Name|message_(hx|sx|pp|mfma)_kernel' "$f" > gpurun_out/${out}_$name.csv
+  grep -E "Counter_Name|$kern" "$f" > gpurun_out/${out}_$name.csv
 }
+CMD=("$@")
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-python3 - "$out" <<'PY'
+python3 - "$out" "${CMD[*]}" <<'PY'
 import csv, json, sys, collections
-out = sys.argv[1]
-acc = collections.defaultdict(list); kern = None
+out, cmd = sys.argv[1], sys.argv[2]
+res = {}
 for part in ("tcc", "fetch", "write", "sq"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(f"gpurun_out/{out}_{part}.csv")):
-        acc[row["Counter_Name"]].append(float(row["Counter_Value"])); kern = row["Kernel_Name"].split("(")[0]
-res = {k: sum(v) / len(v) for k, v in acc.items()}
-res["_kernel"] = kern
-res["_command"] = "rocprofv3 --pmc <counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5 (one pass per counter group; per-launch means)"
-json.dump(res, open(f"gpurun_out/{out}_pmc.json", "w"), indent=1)
-print(json.dumps(res, indent=1))
+        acc[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, cs in acc.items():
+        res.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in cs.items()})
+        res[k]["_launches"] = max(res[k].get("_launches", 0), max(len(v) for v in cs.values()))
+flat = {"_command": f"rocprofv3 --pmc <counters> -- {cmd} (one pass per counter group; per-launch means)"}
+if len(res) == 1:
+    (k, v), = res.items()
+    flat.update(v); flat["_kernel"] = k
+else:
+    flat["kernels"] = res
+json.dump(flat, open(f"gpurun_out/{out}_pmc.json", "w"), indent=1)
+print(json.dumps(flat, indent=1))
 PY
