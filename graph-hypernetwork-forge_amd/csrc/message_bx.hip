@@ -94,7 +94,8 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #define GHF_BX_RD 3          // fold: steps in flight (<= 4)
 #endif
 // Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results): 1 no B refills, 2 no A-tile DMA, 4 no MFMAs,
-// 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table)
+// 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table), 128 one
+// relation's weights for every chunk
 #ifndef GHF_BXEXP
 #define GHF_BXEXP 0
 #endif
@@ -103,6 +104,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #endif
 #ifndef GHF_BX_PK
 #define GHF_BX_PK 1          // fold: v_pk_add_f32 (two per 16 bytes) instead of four v_add_f32: 3.56 -> 3.52 ms at C3
+#endif
+#ifndef GHF_BX_YT
+#define GHF_BX_YT 0
 #endif
 #ifndef GHF_BX_CR
 #define GHF_BX_CR 76         // rows per chunk
@@ -139,6 +143,8 @@ template <> struct BxCfg<128> {
     static constexpr int U = GHF_BX_U, UW = GHF_BX_UW, CR = GHF_BX_CR;
     static constexpr int BN = 2 * U * UW;          // 4 helper waves x 64 lanes x U units x UW positions / 128
     static constexpr int MTC = (CR + 15) / 16;     // row tiles per chunk
+    static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
+    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 32;
 };
 
 struct BxChunk { int r; int e0; int rows; };
@@ -173,8 +179,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr int RBW = (RBN + TW - 1) / TW;  // pieces per helper wave and plane
     constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
     static_assert(NTW == 2 && CR % 4 == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
-    // P0[2] source-row tiles, P1[2] destination-row tiles; a chunk's staged rows Y overwrite its own P1 tile
-    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, TAB_OFF = 4 * TILE, META_OFF = TAB_OFF + BN * 4,
+    // P0[2] source-row tiles, P1[2] destination-row tiles; a chunk's staged rows Y overwrite its own P1 tile — or, where
+    // five tiles fit (YT: rows per chunk <= 60), have a tile of their own: then neither DMA waits for the fold
+    constexpr bool YT = C::YT;
+    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 4 * TILE, TAB_OFF = (YT ? 5 : 4) * TILE, META_OFF = TAB_OFF + BN * 4,
                        DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: 128 bytes of zeros
                        FLAG_OFF = ZERO_OFF + 128;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read)
 
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // overwrite Y at the end of stage (k,1), that the fold of the previous chunk's rows is complete.
         auto fold_prep = [&](int j, int rows, int lane, int (&ri)[U]) {
             const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
-            const unsigned Y = lds0 + P1_OFF + (unsigned)(j & 1) * TILE;
+            const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
             // 1. runs of equal destinations owned by this wave: add row r into row r + 1, ascending
 #pragma unroll
             for (int pass = 0; pass < (CR + 63) / 64; ++pass) {
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         };
         auto fold_units = [&](int j, auto k_lo, auto k_hi, int lane, const int (&ri)[U]) {
             constexpr int K0 = decltype(k_lo)::value, K1 = decltype(k_hi)::value;
-            const unsigned Y = lds0 + P1_OFF + (unsigned)(j & 1) * TILE;
+            const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
             // the unit's bytes in Y (a lane whose node has no row in this chunk reads — and adds — zeros: no branch)
             unsigned ua[U];
 #pragma unroll
@@ -581,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
             dma_tile(P0_OFF + ((k + 1) & 1) * TILE, k + 1, 2, ch[1].rows, true, l0);
+            if (YT) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l0);
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
                 fold_prep(k - 1, prev_rows, l0, ri);
@@ -589,19 +598,25 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_LGKM0();
             if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k + 1);   // this wave is through with Y(k-1) and the table
             BX_STAMP(2);
+            // the table of chunk k is written by all helper waves for all of them: every wave must have read (and cleared)
+            // its entries of chunk k-1 first; without a tile of their own the staged rows also sit where the next
+            // destination rows go
             wait_flags(lds0 + FLAG_OFF, k + 1);
             BX_STAMP(3);
             const int l1 = opaque_lane(lane);
-            dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l1);
-            BX_STAMP(1);
+            // the next requests of the descriptor pipeline: behind the loops above (a load in flight across a loop makes hipcc
+            // wait for everything — the source-row DMA included — at the loop), ahead of the rest of the chunk (requested
+            // at its end they were waited for right behind the next barrier)
             if (!(GHF_BXEXP & 64)) {
-                table_write(k, ch[0].rows, l1);
                 scN = load_scales(ch[3], wdN);
                 wdL = load_words(ch[4], l1);
             }
             d5 = load_desc(k + 5);
+            if (!YT) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l1);
+            BX_STAMP(1);
+            if (!(GHF_BXEXP & 64)) table_write(k, ch[0].rows, l1);
             prev_rows = ch[0].rows;
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // both tiles of chunk k+1 have landed (5 requests younger)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both tiles of chunk k+1 have landed
             BX_LGKM0();
             BX_STAMP(4);
         }
@@ -647,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         const uint32_t wsc_off = (uint32_t)((uint64_t)R * 2 * D * D * (NPL * 2));
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wsplit, 0, (int)wsc_off, 0x00020000);
         auto b_soff = [&](int r, int ph, int t) -> int {
+            if (GHF_BXEXP & 128) r = 0;                    // (timing experiment: one relation's weights, always hot in L2)
             return __builtin_amdgcn_readfirstlane((((r * NT + tw * NTW + t) * NKS + ph * KS) * NPL) * 1024);
         };
         const int lane16 = lane * 16;
@@ -788,16 +804,17 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             load_rel_words(nx.r, wscale_n, bias_n);
             stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, 0, bias_v);
             BX_STAMP(2);
-            // the chunk's rows overwrite its destination-row tile once every consumer wave has read it
-            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k + 1);
+            // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
+            // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it
+            if (!YT && lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k + 1);
             for (;;) {
                 i32x4 f;
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 16) : "memory");
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + (YT ? 0 : 16)) : "memory");
                 const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!(GHF_BXEXP & 16)) write_rows(mt, P1_OFF + (k & 1) * TILE);
+            if (!(GHF_BXEXP & 16)) write_rows(mt, YT ? Y_OFF : P1_OFF + (k & 1) * TILE);
             else
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
@@ -825,8 +842,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 template <int D>
 static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     using C = BxCfg<D>;
-    constexpr int CRP = 16 * C::MTC;
-    constexpr size_t lds = (size_t)4 * 2 * C::CR * (D * 2) + (size_t)C::BN * 4 + 4 * (4 * CRP + 4) * 4 + 1024 + 128 + 32;
+    constexpr size_t lds = C::LDS;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((size_t)(C::BN / 2) * D * 4 <= (size_t)3 * 2 * C::CR * (D * 2), "the tail's dump of half a block must fit the three A tiles");
     GHF_REQUIRE(a.block_nodes == C::BN, "message(bx): plan block_nodes=%d, kernel for d=%d needs %d", a.block_nodes, D, C::BN);

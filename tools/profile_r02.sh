@@ -12,7 +12,7 @@ stats() {  # name, command...
   timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/_kt_$name -o p --output-format csv -- "$@" > gpurun_out/_kt_$name.log 2>&1
   f=$(find gpurun_out/_kt_$name -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/r02/r02_${name}_kernel_stats.csv
-  tail -1 gpurun_out/_kt_$name.log > gpurun_out/r02/r02_${name}.json
+  grep -E "^\{" gpurun_out/_kt_$name.log | tail -1 > gpurun_out/r02/r02_${name}.json
 }
 stats bench_c3 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel-reps 10
 tools/pmc.sh r02_message_kernel 'message_bx_kernel' > /dev/null && cp gpurun_out/r02_message_kernel_pmc.json gpurun_out/r02_message_kernel_*.csv gpurun_out/r02/
