@@ -20,9 +20,11 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
+GHF_FLAG_ZERO_SRC = 4
+GHF_FLAG_ZERO_DST = 8
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
 WLAYOUT_FRAG16 = 1
@@ -48,7 +50,8 @@ SIGNATURES = {
     "ghf_text_encode_fwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ghf_message_layer_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
                                      _vp, _vp, _vp, _i32,
-                                     _vp, _vp, _f32, _i64, _i64, _vp, _vp, _i32, _vp]),
+                                     _vp, _vp, _f32, _i64, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "ghf_message_side_output_supported": (_i32, [_i32, _i32, _i32]),
     "ghf_split_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _i32, _vp, _vp]),
     "ghf_split_rows_bytes": (_sz, [_i64, _i32, _i32]),
     "ghf_weights_bytes": (_sz, [_i32, _i32, _i32, _i32]),
@@ -320,10 +323,12 @@ def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Option
                       bias: torch.Tensor, wlayout: int, ln_gamma: Optional[torch.Tensor],
                       ln_beta: Optional[torch.Tensor], ln_eps: float, h_out: torch.Tensor,
                       row0: int = 0, rows: Optional[int] = None, flags: int = 0,
-                      h_split: Optional[torch.Tensor] = None, h_split_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      h_split: Optional[torch.Tensor] = None, h_split_out: Optional[torch.Tensor] = None,
+                      agg_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`plan` is a plan.GraphPlan: the device arrays, the host copy of the item offsets and the split-block scratch.
     SPLIT3 / SPLIT2H plans gather from `h_split` (split_rows(h, wlayout); made here when the caller has none) and can
-    emit the split form of the rows they write into `h_split_out` for the next layer."""
+    emit the split form of the rows they write into `h_split_out` for the next layer; `agg_out` (side_output_supported)
+    also receives the aggregate before the tail."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
@@ -336,10 +341,15 @@ def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Option
                                      _ptr(plan.indeg), _ptr(plan.chunk_tab), _ptr(plan.blk_chunk_off), _ptr(plan.item_tab),
                                      _ptr(plan.blk_item_off), item0, n_items, _ptr(partial), plan.E, plan.R,
                                      plan.block_nodes, _ptr(W_msg), _ptr(W_self), _ptr(bias), wlayout, _ptr(ln_gamma),
-                                     _ptr(ln_beta), float(ln_eps), row0, rows, _ptr(h_out), _ptr(h_split_out), flags,
+                                     _ptr(ln_beta), float(ln_eps), row0, rows, _ptr(h_out), _ptr(h_split_out), _ptr(agg_out), flags,
                                      _stream()),
            "ghf_message_layer_fwd")
     return h_out
+
+
+def side_output_supported(plan, d: int) -> bool:
+    """Whether the plan's message kernel can also write the aggregate before the tail (message_layer_fwd's agg_out)."""
+    return bool(load().ghf_message_side_output_supported(d, plan.block_nodes, plan.wlayout))
 
 
 def score_pairs_fwd(a: torch.Tensor, b: torch.Tensor, ia: Optional[torch.Tensor] = None,

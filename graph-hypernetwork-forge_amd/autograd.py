@@ -14,8 +14,10 @@ and ``g' = dL/dh'``:
     dh = dpre + [sum_{e->v} G_v Ws[r]^T]_v + [sum_{e: src=u} G_{dst(e)} Wm[r]^T]_u
          (two ghf_message_layer_fwd passes with GHF_FLAG_RAW_SUM: transposed weights on the plan / on the reversed plan)
 
-First version: exact fp32 contractions for the weight gradients, the message kernel for the h gradients; the
-training forward runs the message kernel with GHF_FLAG_NO_TAIL plus ``ghf_tail_fwd`` so that ``out`` can be saved.
+Exact fp32 contractions for the weight gradients, the message kernel for the h gradients (each of its two passes has one
+zero half of the weights and says so: GHF_FLAG_ZERO_SRC / GHF_FLAG_ZERO_DST).  The training forward is the inference
+launch with one more store: the kernel writes ``out`` beside ``h'`` (``agg_out``) and the split rows the next layer
+gathers; kernels without that side output run GHF_FLAG_NO_TAIL plus ``ghf_tail_fwd``.
 
 The callers either side of the layer have their own Functions here: ``WeightGeneratorFn`` (three MLP heads and the
 learnable log-scales, reference weight_generator.py:120-143), ``InputProjFn`` (hypergnn.py:261), ``TextEncoderFn``
@@ -25,6 +27,7 @@ i.e. ``ghf_group_outer`` again (``_native.matmul_tn``).
 
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -44,6 +47,7 @@ class TrainPlan:
     goff: torch.Tensor            # [R+1] int64
     slice_tab: Optional[torch.Tensor] = None   # [S, 3] int64 (relation, first edge, end edge): ghf_edge_outer's work list
     slice_off: Optional[torch.Tensor] = None   # [R+1] int64
+    carry: Optional["_SplitCarry"] = None       # split rows handed from one layer's launch to the next
 
 SLICE_EDGES = 4096                # edges per ghf_edge_outer workgroup (a multiple of its 32-edge tile)
 
@@ -58,7 +62,7 @@ def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: Graph
     perm, goff = _native.group_edges(rel.index_select(0, by_dst), fwd.R)   # hot in L2 while a slice is contracted
     perm = by_dst.index_select(0, perm)
     tp = TrainPlan(fwd=fwd, rev=rev, src_by_rel=ei[0].index_select(0, perm).contiguous(),
-                   dst_by_rel=ei[1].index_select(0, perm).contiguous(), goff=goff)
+                   dst_by_rel=ei[1].index_select(0, perm).contiguous(), goff=goff, carry=_SplitCarry())
     if _native.load().ghf_edge_outer_supported(d):
         off = goff.cpu().tolist()                             # (one host sync per plan)
         tab, soff = [], [0]
@@ -106,8 +110,27 @@ def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, fl
     return out
 
 
-def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor) -> torch.Tensor:
-    return _message(x, plan, W, W_self, zero_bias, _native.GHF_FLAG_RAW_SUM)
+def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor, zero_half: int) -> torch.Tensor:
+    return _message(x, plan, W, W_self, zero_bias, _native.GHF_FLAG_RAW_SUM | zero_half)
+
+
+class _SplitCarry:
+    """The split form of a layer's output rows, written by that layer's launch for the next layer's gathers (the
+    inference path's h_split chain).  Valid for the very tensor object the launch returned, unmodified since — anything
+    else (another tensor, an in-place edit) finds nothing and the rows are cut again."""
+
+    def __init__(self) -> None:
+        self.ref = None
+        self.version = -1
+        self.split = None
+
+    def take(self, h: torch.Tensor):
+        hit = self.ref is not None and self.ref() is h and h._version == self.version
+        split, self.ref, self.split = (self.split if hit else None), None, None
+        return split
+
+    def put(self, h: torch.Tensor, split: torch.Tensor) -> None:
+        self.ref, self.version, self.split = weakref.ref(h), h._version, split
 
 
 class MessageLayerFn(torch.autograd.Function):
@@ -118,9 +141,19 @@ class MessageLayerFn(torch.autograd.Function):
         plan = tp.fwd
         h = h.contiguous()
         W, W2 = _layer_weights(plan, W_msg.detach(), W_self.detach(), transpose=False)
-        agg = _message(h, plan, W, W2, bias.detach().contiguous(), _native.GHF_FLAG_NO_TAIL)
         out = torch.empty_like(h)
-        _native.tail_fwd(agg, h, gamma.detach(), beta.detach(), eps, out)
+        if _native.side_output_supported(plan, h.size(1)):             # one launch: h', the aggregate, the next layer's split rows
+            agg = torch.empty_like(h)
+            hs = tp.carry.take(h)
+            if hs is None:
+                hs = _native.split_rows(h, plan.wlayout)
+            hs_out = torch.empty_like(hs)
+            _native.message_layer_fwd(h, plan, W, W2, bias.detach().contiguous(), plan.wlayout, gamma.detach(), beta.detach(), eps,
+                                      out, h_split=hs, h_split_out=hs_out, agg_out=agg)
+            tp.carry.put(out, hs_out)
+        else:
+            agg = _message(h, plan, W, W2, bias.detach().contiguous(), _native.GHF_FLAG_NO_TAIL)
+            _native.tail_fwd(agg, h, gamma.detach(), beta.detach(), eps, out)
         ctx.save_for_backward(h, agg, W_msg, W_self, gamma)
         ctx.tp, ctx.eps = tp, eps
         return out
@@ -147,7 +180,8 @@ class MessageLayerFn(torch.autograd.Function):
             zero_b = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)
             Wf, Wf2 = _layer_weights(plan, None, W_self.detach(), transpose=True)       # self term: rows keyed by destination
             Wr, Wr2 = _layer_weights(tp.rev, W_msg.detach(), None, transpose=True)      # message term: scattered to the sources
-            dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b), _raw_message(G, tp.rev, Wr, Wr2, zero_b), out=dpre)
+            dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC),
+                              _raw_message(G, tp.rev, Wr, Wr2, zero_b, _native.GHF_FLAG_ZERO_DST), out=dpre)
         return dh, dWm, dWs, db, dgamma, dbeta, None, None
 
 

@@ -153,13 +153,17 @@ int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows,
     return set_err(GHF_EINVAL, "split_rows: layout %d gathers h itself", wlayout);
 }
 
+int ghf_message_side_output_supported(int d, int block_nodes, int wlayout) {
+    return wlayout == GHF_WLAYOUT_SPLIT2H && message_bx_owns(d, block_nodes) ? 1 : 0;
+}
+
 int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d, const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg, const int32_t* chunk_tab,
                           const int32_t* blk_chunk_off, const int32_t* item_tab, const int32_t* blk_item_off,
                           int64_t item0, int64_t n_items, float* partial, int64_t E, int R, int block_nodes,
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0, int64_t rows,
-                          float* h_out, void* h_split_out, int flags, void* stream) {
+                          float* h_out, void* h_split_out, float* agg_out, int flags, void* stream) {
     GHF_REQUIRE(h && sorted_key && sorted_src && seg_off && indeg && W_msg && bias && h_out,
                 "message_layer_fwd: null pointer argument");
     if (flags & GHF_FLAG_RAW_SUM) flags |= GHF_FLAG_NO_TAIL;
@@ -177,7 +181,12 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
                 "message_layer_fwd: h_split_out needs split weights and the fused tail, and must not alias h_split");
     MsgArgs a{h, h_split, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, item0, n_items,
               partial, E, R, block_nodes, W_msg, W_self, bias, wlayout,
-              ln_gamma, ln_beta, ln_eps, row0, rows, h_out, h_split_out, flags};
+              ln_gamma, ln_beta, ln_eps, row0, rows, h_out, h_split_out, flags, agg_out};
+    GHF_REQUIRE((flags & (GHF_FLAG_ZERO_SRC | GHF_FLAG_ZERO_DST)) != (GHF_FLAG_ZERO_SRC | GHF_FLAG_ZERO_DST),
+                "message_layer_fwd: GHF_FLAG_ZERO_SRC and GHF_FLAG_ZERO_DST together leave nothing to compute");
+    GHF_REQUIRE(!agg_out || (!(flags & GHF_FLAG_NO_TAIL) && agg_out != h_out), "message_layer_fwd: agg_out goes with the fused tail and must not alias h_out");
+    if (agg_out && !ghf_message_side_output_supported(d, block_nodes, wlayout))
+        return set_err(GHF_EUNSUPPORTED, "message_layer_fwd: no side output from the kernel for d=%d, block_nodes=%d, layout %d", d, block_nodes, wlayout);
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT2H && message_bx_owns(d, block_nodes)) return launch_message_bx(a, (hipStream_t)stream);

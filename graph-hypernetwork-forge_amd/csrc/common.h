@@ -160,6 +160,7 @@ struct MsgArgs {
     const float* W_msg; const float* W_self; const float* bias; int wlayout;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     int64_t row0; int64_t rows; float* h_out; void* h_split_out; int flags;
+    float* agg_out;              // optional side output: the aggregate before the tail (ghf.h)
 };
 int launch_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
 int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);

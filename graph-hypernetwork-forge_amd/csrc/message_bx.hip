@@ -149,7 +149,9 @@ template <> struct BxCfg<128> {
 
 struct BxChunk { int r; int e0; int rows; };
 
-template <int D>
+// SKIP: bit 0 = the source half of the weights is zero (GHF_FLAG_ZERO_SRC), bit 1 = the destination half: that half's gathers
+// and products are compiled out (a run-time switch cost the consumers' loop a spilled weight fragment)
+template <int D, int SKIP>
 __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     const float* __restrict__ h, const void* __restrict__ h_split, int64_t N, const uint32_t* __restrict__ sorted_key,
     const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
@@ -158,8 +160,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     const void* __restrict__ Wsplit, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail,
-    int32_t* __restrict__ range_flag) {
+    int32_t* __restrict__ range_flag, float* __restrict__ agg_out) {
     using C = BxCfg<D>;
+    constexpr int skip = SKIP;
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, U = C::U, UW = C::UW;
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
     constexpr int KS = D / 32;                // k-steps of 32 per phase
@@ -284,6 +287,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 const int nl = node_of(v);
                 const bool live = g < NG && nl < nrows;
                 const f32x4 a0 = *(const f32x4*)(acc_lds + v * D + c0), a1 = *(const f32x4*)(acc_lds + v * D + c0 + 4);
+                if (agg_out && live) {                   // side output: the mean before the tail (what the backward keeps)
+                    float* __restrict__ o = agg_out + (size_t)(node0 + nl) * D + c0;
+                    *(f32x4*)o = a0 * inv[gb];
+                    *(f32x4*)(o + 4) = a1 * inv[gb];
+                }
                 float y[8];
                 float s = 0.f;
 #pragma unroll
@@ -566,8 +574,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0 and 1 visible to all helper waves
         // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
         if (nchunks > 0) {
-            dma_tile(P0_OFF, 0, 2, ch[0].rows, true, lane);
-            dma_tile(P1_OFF, 0, 3, ch[0].rows, false, lane);
+            if (!(skip & 1)) dma_tile(P0_OFF, 0, 2, ch[0].rows, true, lane);
+            if (!(skip & 2)) dma_tile(P1_OFF, 0, 3, ch[0].rows, false, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         int ri[U];
@@ -588,8 +596,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
-            dma_tile(P0_OFF + ((k + 1) & 1) * TILE, k + 1, 2, ch[1].rows, true, l0);
-            if (YT) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l0);
+            if (!(skip & 1)) dma_tile(P0_OFF + ((k + 1) & 1) * TILE, k + 1, 2, ch[1].rows, true, l0);
+            if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l0);
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
                 fold_prep(k - 1, prev_rows, l0, ri);
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 wdL = load_words(ch[4], l1);
             }
             d5 = load_desc(k + 5);
-            if (!YT) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l1);
+            if (!YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l1);
             BX_STAMP(1);
             if (!(GHF_BXEXP & 64)) table_write(k, ch[0].rows, l1);
             prev_rows = ch[0].rows;
@@ -776,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
         };
 
+        const int ph_first = skip & 1;                     // the first live phase of a chunk
         BxChunk ch{0, 0, 1};
         i32x2 dn{0, 0};
         float bias_v[NTW] = {}, bias_n[NTW] = {}, wscale = 1.f, wscale_n = 1.f;
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             dn = load_desc(1);
             load_rel_words(ch.r, wscale, bias_v);
 #pragma unroll
-            for (int j = 0; j < KS; ++j) load_b_step(ch.r, 0, j);
+            for (int j = 0; j < KS; ++j) load_b_step(ch.r, ph_first, j);
         }
         __syncthreads();                                   // barrier A
         for (int k = 0; k < nchunks; ++k) {
@@ -798,11 +807,18 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             __syncthreads();                               // ---- chunk k
             BX_STAMP(0);
             const BxChunk nx = decode(dn);
-            stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, ch.r, 1, bias_v);
+            // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
+            if (!(skip & 1)) stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v);
             BX_STAMP(1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
-            stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, 0, bias_v);
+            if (skip & 1) {                                // no source phase ran: the destination phase adds to the bias
+#pragma unroll
+                for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){bias_v[t], bias_v[t], bias_v[t], bias_v[t]};
+            }
+            if (!(skip & 2)) stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v);
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
             // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it
@@ -855,13 +871,21 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     GHF_REQUIRE((uint64_t)a.N * (D * 4 + 4) < (1ull << 31) && (uint64_t)a.E * 4 < (1ull << 32) &&
                     (uint64_t)a.R * (2 * D * D * 4 + 4) < (1ull << 32),
                 "message(bx): 32-bit byte offsets need N*(4d+4) below 2 GiB, E*4 and R*(8d*d+4) below 4 GiB");
-    GHF_SET_MAX_LDS(message_bx_kernel<D>, lds);
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(bx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(bx): split blocks need the `partial` scratch");
-    message_bx_kernel<D><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
-                                                                   a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
-                                                                   a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
-                                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr());
+    const int skip = ((a.flags & GHF_FLAG_ZERO_SRC) ? 1 : 0) | ((a.flags & GHF_FLAG_ZERO_DST) ? 2 : 0);
+    auto go = [&](auto skip_c) {
+        constexpr int S = decltype(skip_c)::value;
+        GHF_SET_MAX_LDS((message_bx_kernel<D, S>), lds);
+        message_bx_kernel<D, S><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
+                                                                          a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
+                                                                          a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
+                                                                          a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr(), a.agg_out);
+        return GHF_OK;
+    };
+    if (skip == 1) go(std::integral_constant<int, 1>{});
+    else if (skip == 2) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 0>{});
     GHF_LAUNCH_CHECK();
     if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
     return GHF_OK;

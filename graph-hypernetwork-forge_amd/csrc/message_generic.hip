@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
     const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off,
     const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
     const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int64_t row_end,
-    float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail, int32_t* __restrict__ range_flag) {
+    float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail, int32_t* __restrict__ range_flag,
+    float* __restrict__ agg_out) {
     const int64_t blk = blk0 + blockIdx.x;
     const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
     if (i1 - i0 <= 1) return;
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
                 }
                 for (; j < nslots; ++j) t0 += p[(size_t)j * sstr];
                 float t = ((t0 + t1) + (t2 + t3)) * inv;
+                if (agg_out) agg_out[(size_t)node * d + o] = t;
                 x[c] = no_tail ? t : fmaxf(t + h[(size_t)node * d + o], 0.f);
                 s += x[c];
             }
@@ -233,7 +235,7 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)cdiv(a.rows, a.block_nodes), (unsigned)cdiv(a.block_nodes, COMB_ROWS));
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
                                                    a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, a.h_split_out, a.wlayout,
-                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr());
+                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr(), a.agg_out);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 9
+#define GHF_ABI_VERSION 10
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -39,6 +39,10 @@ extern "C" {
 /* ghf_message_layer_fwd flags */
 #define GHF_FLAG_NO_TAIL  1   /* write sum_e(...) / max(indeg,1) only: skip residual+ReLU+LayerNorm */
 #define GHF_FLAG_RAW_SUM  2   /* (implies NO_TAIL) write sum_e(...) itself, no division: the backward passes */
+#define GHF_FLAG_ZERO_SRC 4   /* the caller states that the source half of every relation's weights (W_msg) is zero: a kernel
+                                 may skip the source-row gathers and their products (the two gradient passes of the backward
+                                 each have one zero half); the result is the same with or without the flag */
+#define GHF_FLAG_ZERO_DST 8   /* the same for the destination half (W_self); not both */
 
 /* Weight layouts produced by ghf_weightgen_fwd and consumed by ghf_message_layer_fwd */
 #define GHF_WLAYOUT_NATURAL 0 /* W_msg[R][d_in][d_out], W_self[R][d_in][d_out] row-major, as the reference returns them */
@@ -137,7 +141,11 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
  * status[2]*BN*d floats for the split blocks (may be NULL when status[2] == 0).
  * h_split: the rows of h cut into pieces by ghf_split_rows (or by a previous call's h_split_out); required when
  * wlayout is SPLIT3 or SPLIT2H, ignored otherwise.  h_split_out (optional, those layouts only, not with
- * GHF_FLAG_NO_TAIL): receives the split form of the h_out rows written by this call, for the next layer. */
+ * GHF_FLAG_NO_TAIL): receives the split form of the h_out rows written by this call, for the next layer.
+ * agg_out (optional, not with GHF_FLAG_NO_TAIL; ghf_message_side_output_supported): also receives, for the rows written,
+ * the aggregate before the tail — what GHF_FLAG_NO_TAIL would have written to h_out — which a training forward keeps for
+ * ghf_tail_bwd (the reference's autograd keeps the same tensor, hypergnn.py:281-296). */
+int ghf_message_side_output_supported(int d, int block_nodes, int wlayout);
 int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* ghf_split_rows output or NULL */, int64_t N, int d,
                           const uint32_t* sorted_key, const int32_t* sorted_src,
                           const int32_t* seg_off, const int32_t* indeg,
@@ -148,7 +156,7 @@ int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* ghf
                           const float* W_msg, const float* W_self, const float* bias, int wlayout,
                           const float* ln_gamma, const float* ln_beta, float ln_eps,
                           int64_t row0, int64_t rows, float* h_out /* [N,d] */,
-                          void* h_split_out /* or NULL */, int flags, void* stream);
+                          void* h_split_out /* or NULL */, float* agg_out /* [N,d] or NULL */, int flags, void* stream);
 
 /* Rows [row0, row0+rows) of h [N,d] in the form the message kernel of `wlayout` gathers (the split is done once per
  * row here instead of once per edge there); h_split holds ghf_split_rows_bytes(N, d, wlayout) bytes:

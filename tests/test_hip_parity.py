@@ -475,6 +475,44 @@ def test_split_hub_blocks_match_oracle(d, kernel):
         assert (part[:bn] == 7.0).all() and (part[4 * bn:] == 7.0).all()
 
 
+@pytest.mark.parametrize("N,E,R,kind", [(3000, 30000, 64, "uniform"), (6000, 150000, 8, "powerlaw")])
+def test_side_output_and_zero_half_flags(N, E, R, kind):
+    """What the training path adds to the d = 128 launch (ghf.h): agg_out — the aggregate before the tail, written beside h'
+    and the split rows by the same launch (split hub blocks included) — is bit for bit the GHF_FLAG_NO_TAIL output and
+    leaves h' unchanged; GHF_FLAG_ZERO_SRC / ZERO_DST on weights whose half really is zero change nothing but the time."""
+    d = 128
+    ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=515 + R, kind=kind)
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    assert _native.side_output_supported(plan, d)
+    W, h_d = _pack_weights(plan, Wm, Ws)[0], t(h)
+    hs = _native.split_rows(h_d, plan.wlayout)
+    plain, plain_split = torch.empty_like(h_d), torch.empty_like(hs)
+    _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, plain, h_split=hs, h_split_out=plain_split)
+    no_tail = torch.empty_like(h_d)
+    _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, None, None, 0.0, no_tail, h_split=hs, flags=_native.GHF_FLAG_NO_TAIL)
+    out, agg, split = torch.empty_like(h_d), torch.full_like(h_d, float("nan")), torch.empty_like(hs)
+    _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, out, h_split=hs, h_split_out=split, agg_out=agg)
+    assert torch.equal(out, plain) and torch.equal(split.view(torch.uint8), plain_split.view(torch.uint8))
+    assert torch.equal(agg, no_tail)
+    th = torch.from_numpy
+    assert_close(agg.cpu().numpy(), O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b)).numpy(), "agg_out")
+    with pytest.raises(ValueError, match="agg_out"):
+        _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, None, None, 0.0, out, h_split=hs, agg_out=agg, flags=_native.GHF_FLAG_NO_TAIL)
+    # the two gradient passes: one half of the weights is zero
+    zb = torch.zeros(R, d, device=DEV)
+    for top, bottom, flag in ((None, Ws, _native.GHF_FLAG_ZERO_SRC), (Wm, None, _native.GHF_FLAG_ZERO_DST)):
+        Wz = _native.weights_pack(None if top is None else t(top), None if bottom is None else t(bottom), True, R, d, plan.wlayout)
+        for bias in (zb, t(b)):
+            base, fast = torch.empty_like(h_d), torch.full_like(h_d, float("nan"))
+            _native.message_layer_fwd(h_d, plan, Wz, None, bias, plan.wlayout, None, None, 0.0, base, h_split=hs, flags=_native.GHF_FLAG_RAW_SUM)
+            _native.message_layer_fwd(h_d, plan, Wz, None, bias, plan.wlayout, None, None, 0.0, fast, h_split=hs, flags=_native.GHF_FLAG_RAW_SUM | flag)
+            assert torch.equal(fast, base), f"flag {flag}: max diff {float((fast - base).abs().max()):.3e}"
+    with pytest.raises(ValueError, match="nothing to compute"):
+        _native.message_layer_fwd(h_d, plan, W, None, zb, plan.wlayout, None, None, 0.0, out, h_split=hs,
+                                  flags=_native.GHF_FLAG_RAW_SUM | _native.GHF_FLAG_ZERO_SRC | _native.GHF_FLAG_ZERO_DST)
+
+
 @pytest.mark.parametrize("d,N,E,R,kind", [(20, 300, 2500, 5, "powerlaw"), (128, 1200, 9000, 6, "uniform"),
                                           (128, 500, 6000, 3, "powerlaw")])
 def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind):

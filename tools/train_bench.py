@@ -48,6 +48,8 @@ def main():
 
     def step(split=None):
         model.zero_grad(set_to_none=True)
+        if split is not None:
+            torch.cuda.synchronize()                      # the previous step's backward is still running otherwise
         t0 = time.perf_counter()
         embs = model.forward_ids(x, edge_index, rel, names)
         pos = model.score_triple(embs[src], embs[dst])
