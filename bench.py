@@ -59,8 +59,7 @@ def layer_flops(N, E, R, d):
 
 def kern_name(plan, d):
     from graph_hypernetwork_forge_amd import _native
-    return {_native.WLAYOUT_SPLIT2H: "message_bx_kernel" if plan.block_nodes == 384 else "message_hx_kernel",
-            _native.WLAYOUT_SPLIT3: "message_sx_kernel"}.get(
+    return {_native.WLAYOUT_SPLIT2H: "message_bx_kernel" if plan.block_nodes == 384 else "message_hx_kernel"}.get(
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
@@ -325,12 +324,12 @@ def main():
             traffic = sum((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for v in parts)
             traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2; per-launch means" + \
                           (", summed over the layer's kernels)" if len(parts) > 1 else ")")
-        kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<128>", _native.WLAYOUT_SPLIT3: "message_sx_kernel<128>"}.get(
+        kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<128>"}.get(
             plan.wlayout, "message_pp_kernel<%d>" % d if plan.block_nodes > 1 else "message_generic_kernel")
         if wide:
             kern = "edge_transform_kernel + segment_tail_kernel<%d> (one layer)" % (d // 64)
-        # matrix work the kernel issues per algorithmic flop: 3 fp16 products (hx), 6 bf16 products (sx), 1 fp32 (pp)
-        prod, mpeak = {_native.WLAYOUT_SPLIT2H: (3, F16_MATRIX_PEAK_TF), _native.WLAYOUT_SPLIT3: (6, F16_MATRIX_PEAK_TF)}.get(
+        # matrix work the kernel issues per algorithmic flop: 3 fp16 products (bx, hx), 1 fp32 (pp)
+        prod, mpeak = {_native.WLAYOUT_SPLIT2H: (3, F16_MATRIX_PEAK_TF)}.get(
             plan.wlayout, (1, FP32_MATRIX_PEAK_TF))
         if wide and not _native.rs_exact():
             prod, mpeak = 3, F16_MATRIX_PEAK_TF

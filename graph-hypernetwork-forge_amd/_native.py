@@ -28,9 +28,8 @@ GHF_FLAG_ZERO_DST = 8
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
 WLAYOUT_FRAG16 = 1
-WLAYOUT_SPLIT3 = 2          # bf16 B fragments, 3 exact pieces per weight (6 bytes each) in an opaque float32 buffer
 WLAYOUT_SPLIT2H = 3         # fp16 B fragments, 2 pieces per weight scaled by a power of two per relation (+ the scales)
-SPLIT_LAYOUTS = (WLAYOUT_SPLIT3, WLAYOUT_SPLIT2H)   # layouts whose kernels gather pre-split rows (split_rows)
+SPLIT_LAYOUTS = (WLAYOUT_SPLIT2H,)   # layouts whose kernels gather pre-split rows (split_rows)
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -302,13 +301,13 @@ def alloc_split(N: int, d: int, wlayout: int, device) -> torch.Tensor:
     nbytes = load().ghf_split_rows_bytes(N, d, wlayout)
     if nbytes == 0:
         raise ValueError(f"weight layout {wlayout} gathers h itself")
-    return torch.empty((N, 3, d) if wlayout == WLAYOUT_SPLIT3 else (nbytes // 2,), dtype=torch.int16, device=device)
+    return torch.empty((nbytes // 2,), dtype=torch.int16, device=device)
 
 
 def split_rows(h: torch.Tensor, wlayout: int, out: Optional[torch.Tensor] = None, row0: int = 0,
                rows: Optional[int] = None) -> torch.Tensor:
     """Rows of h in the form the message kernel of `wlayout` gathers (include/ghf.h: ghf_split_rows): an opaque int16
-    tensor — SPLIT3: [N, 3, d] bf16 bit patterns; SPLIT2H: N*2*d fp16 bit patterns followed by N float scales."""
+    tensor — SPLIT2H: N*2*d fp16 bit patterns followed by N float scales."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
@@ -326,7 +325,7 @@ def message_layer_fwd(h: torch.Tensor, plan, W_msg: torch.Tensor, W_self: Option
                       h_split: Optional[torch.Tensor] = None, h_split_out: Optional[torch.Tensor] = None,
                       agg_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`plan` is a plan.GraphPlan: the device arrays, the host copy of the item offsets and the split-block scratch.
-    SPLIT3 / SPLIT2H plans gather from `h_split` (split_rows(h, wlayout); made here when the caller has none) and can
+    SPLIT2H plans gather from `h_split` (split_rows(h, wlayout); made here when the caller has none) and can
     emit the split form of the rows they write into `h_split_out` for the next layer; `agg_out` (side_output_supported)
     also receives the aggregate before the tail."""
     lib = load()
@@ -384,7 +383,7 @@ def prefer_rs(d: int, R: int) -> bool:
     always where no destination-block kernel exists (d >= 256); at d = 128 from about 128 relations on — the block
     kernel re-streams a relation's weights per (block, relation) chunk, so its time grows with R (C3-sized graph: 4.1 ms per
     layer at R = 64, 11.3 ms at 256) while the relation-stationary layer's does not (6.0 ms)."""
-    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("bx", "hx", "sx", "pp", "lockstep"):
+    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("bx", "hx", "pp"):
         return False
     return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
 

@@ -43,9 +43,8 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
     if (!block_nodes || !wlayout || !chunk_rows || !split_chunks) return set_err(GHF_EINVAL, "message_config: null output pointer");
     int bn = 1, cr = 0, sc = 0;
     // GHF_KERNEL selects the d = 128 kernel for A/B runs: "bx" (default) = two fp16 pieces, three products, block sums in
-    // registers (message_bx.hip); "hx" = the same contraction with the block sums in LDS (message_hx.hip); "sx" = three
-    // bf16 pieces, six products (message_sx.hip); "pp" / "lockstep" = v_mfma_f32_16x16x4_f32 (message_pp.hip /
-    // message_mfma.hip)
+    // registers (message_bx.hip); "hx" = the same contraction with the block sums in LDS (message_hx.hip); "pp" = exact fp32,
+    // v_mfma_f32_16x16x4_f32 (message_pp.hip: also what the range guard falls back to)
     // "rs" / "rs32" / "generic": a CSR plan also where a destination-block kernel exists (A/B of the relation-stationary
     // layer at d = 128)
     const char* kv = getenv("GHF_KERNEL");
@@ -64,12 +63,7 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
         *wlayout = GHF_WLAYOUT_SPLIT2H;
         *chunk_rows = cr;
         *split_chunks = sc;
-    } else if (kv && !strcmp(kv, "sx") && message_sx_config(d, &bn, &cr, &sc)) {
-        *block_nodes = bn;
-        *wlayout = GHF_WLAYOUT_SPLIT3;
-        *chunk_rows = cr;
-        *split_chunks = sc;
-    } else if (message_mfma_config(d, &bn, &cr, &sc)) {
+    } else if (message_pp_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_FRAG16;
         *chunk_rows = cr;
@@ -130,7 +124,6 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in, int
 }
 
 size_t ghf_split_rows_bytes(int64_t N, int d, int wlayout) {
-    if (wlayout == GHF_WLAYOUT_SPLIT3) return (size_t)N * d * 6;
     if (wlayout == GHF_WLAYOUT_SPLIT2H) return (size_t)N * d * 4 + (size_t)N * 4;
     return 0;
 }
@@ -139,7 +132,6 @@ size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout) {
     const size_t n = (size_t)R * d_in * d_out;
     switch (wlayout) {
         case GHF_WLAYOUT_FRAG16:  return 2 * n * 4;
-        case GHF_WLAYOUT_SPLIT3:  return 2 * n * 6;
         case GHF_WLAYOUT_SPLIT2H: return 2 * n * 4 + (size_t)R * 4;
         default:                  return n * 4;
     }
@@ -148,7 +140,6 @@ size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout) {
 int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, int wlayout, void* h_split, void* stream) {
     GHF_REQUIRE(h && h_split, "split_rows: null pointer argument");
     GHF_REQUIRE(N > 0 && d > 0 && d % 4 == 0 && row0 >= 0 && rows >= 0 && row0 + rows <= N, "split_rows: bad shape or row range");
-    if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_split3_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_split2h_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
     return set_err(GHF_EINVAL, "split_rows: layout %d gathers h itself", wlayout);
 }
@@ -175,8 +166,8 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     GHF_REQUIRE(row0 % block_nodes == 0, "message_layer_fwd: row0 must be a multiple of block_nodes");
     GHF_REQUIRE(block_nodes == 1 || (chunk_tab && blk_chunk_off && item_tab && blk_item_off && item0 >= 0 && n_items >= 0),
                 "message_layer_fwd: block plans need the chunk and item tables");
-    const bool split = wlayout == GHF_WLAYOUT_SPLIT3 || wlayout == GHF_WLAYOUT_SPLIT2H;
-    GHF_REQUIRE(!split || h_split, "message_layer_fwd: SPLIT3 / SPLIT2H weights need h_split (ghf_split_rows)");
+    const bool split = wlayout == GHF_WLAYOUT_SPLIT2H;
+    GHF_REQUIRE(!split || h_split, "message_layer_fwd: SPLIT2H weights need h_split (ghf_split_rows)");
     GHF_REQUIRE(!h_split_out || (split && !(flags & GHF_FLAG_NO_TAIL) && h_split_out != h_split),
                 "message_layer_fwd: h_split_out needs split weights and the fused tail, and must not alias h_split");
     MsgArgs a{h, h_split, N, d, sorted_key, sorted_src, seg_off, indeg, chunk_tab, blk_chunk_off, item_tab, blk_item_off, item0, n_items,
@@ -188,10 +179,10 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     if (agg_out && !ghf_message_side_output_supported(d, block_nodes, wlayout))
         return set_err(GHF_EUNSUPPORTED, "message_layer_fwd: no side output from the kernel for d=%d, block_nodes=%d, layout %d", d, block_nodes, wlayout);
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
-    if (wlayout == GHF_WLAYOUT_SPLIT3) return launch_message_sx(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT2H && message_bx_owns(d, block_nodes)) return launch_message_bx(a, (hipStream_t)stream);
     if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_message_hx(a, (hipStream_t)stream);
-    return launch_message_mfma(a, (hipStream_t)stream);
+    GHF_REQUIRE(wlayout == GHF_WLAYOUT_FRAG16, "message_layer_fwd: unknown weight layout %d", wlayout);
+    return launch_message_pp(a, (hipStream_t)stream);
 }
 
 size_t ghf_group_workspace_bytes(int64_t E) { return group_workspace_bytes(E); }

@@ -142,14 +142,6 @@ int launch_text_encode(const int32_t* ids, const int32_t* lens, int U, int Lmax,
 int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
                       float* h0, void* h_split, int split_layout, hipStream_t stream);
 
-// x = p[0] + p[1] + p[2] exactly, p[i] = the i-th group of 8 significand bits as a bf16 bit pattern (truncation)
-__device__ __forceinline__ void split3_pieces(float x, uint16_t (&p)[3]) {
-    const uint32_t u1 = __float_as_uint(x);
-    const float r1 = x - __uint_as_float(u1 & 0xFFFF0000u);
-    const uint32_t u2 = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(u2 & 0xFFFF0000u);
-    p[0] = (uint16_t)(u1 >> 16); p[1] = (uint16_t)(u2 >> 16); p[2] = (uint16_t)(__float_as_uint(r2) >> 16);
-}
 
 struct MsgArgs {
     const float* h; const void* h_split; int64_t N; int d;
@@ -162,7 +154,6 @@ struct MsgArgs {
     int64_t row0; int64_t rows; float* h_out; void* h_split_out; int flags;
     float* agg_out;              // optional side output: the aggregate before the tail (ghf.h)
 };
-int launch_split3_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
 int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
 int launch_message_hx(const MsgArgs& a, hipStream_t stream);       // fp16 two-piece contraction (d = 128), SPLIT2H weights
 bool message_hx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
@@ -170,11 +161,8 @@ int launch_message_bx(const MsgArgs& a, hipStream_t stream);       // the same c
 bool message_bx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 bool message_bx_owns(int d, int block_nodes);                      // whether a SPLIT2H plan of this geometry is message_bx's
 int launch_message_generic(const MsgArgs& a, hipStream_t stream);
-int launch_message_mfma(const MsgArgs& a, hipStream_t stream);     // returns GHF_EUNSUPPORTED if no tuned kernel
-int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // ping-pong schedule (d = 128)
-bool message_mfma_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
-int launch_message_sx(const MsgArgs& a, hipStream_t stream);       // split-bf16 contraction (d = 128), SPLIT3 weights
-bool message_sx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
+int launch_message_pp(const MsgArgs& a, hipStream_t stream);       // exact fp32 MFMA, ping-pong schedule (d = 128, 64), FRAG16 weights
+bool message_pp_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 int launch_combine_split(const MsgArgs& a, hipStream_t stream);     // sums the partial slots of split blocks + tail
 
 size_t group_workspace_bytes(int64_t E);

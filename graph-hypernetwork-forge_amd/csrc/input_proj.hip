@@ -141,8 +141,7 @@ __global__ __launch_bounds__(256) void input_proj_simple_kernel(const float* __r
 int launch_input_proj(const float* x, const float* W_in, const float* b_in, int64_t N, int F, int d,
                       float* h0, void* h_split, int split_layout, hipStream_t stream) {
     GHF_REQUIRE(N > 0 && F > 0 && d > 0, "input_proj: N, F, d must be positive");
-    GHF_REQUIRE(!h_split || split_layout == GHF_WLAYOUT_SPLIT2H || split_layout == GHF_WLAYOUT_SPLIT3,
-                "input_proj: h_split needs a split weight layout, got %d", split_layout);
+    GHF_REQUIRE(!h_split || split_layout == GHF_WLAYOUT_SPLIT2H, "input_proj: h_split needs the SPLIT2H layout, got %d", split_layout);
     const bool fuse = h_split && split_layout == GHF_WLAYOUT_SPLIT2H;
     const bool aligned = ((((uintptr_t)x | (uintptr_t)W_in) & 15) == 0);
     const bool mfma_ok = aligned && (F % 16) == 0 && (d % 16) == 0 && d <= 256;
@@ -165,8 +164,7 @@ int launch_input_proj(const float* x, const float* W_in, const float* b_in, int6
     }
     GHF_LAUNCH_CHECK();
     if (h_split && !(fuse && mfma_ok)) {                  // shapes / layouts without the fused epilogue: a separate pass
-        if (split_layout == GHF_WLAYOUT_SPLIT2H) return launch_split2h_rows(h0, N, d, 0, N, h_split, stream);
-        return launch_split3_rows(h0, N, d, 0, N, h_split, stream);
+        return launch_split2h_rows(h0, N, d, 0, N, h_split, stream);
     }
     return GHF_OK;
 }

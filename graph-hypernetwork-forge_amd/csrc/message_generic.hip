@@ -9,7 +9,7 @@
 // Lanes own output columns o (coalesced reads of W[r][i][:]); h_u and h_v sit in LDS.
 // Edges arrive sorted by (dst, rel), so the summation order is fixed: results are
 // bitwise reproducible run to run.
-// This is the correctness-first kernel; the MFMA kernel in message_mfma.hip takes over
+// This is the correctness-first kernel; the MFMA kernels (message_bx.hip, message_pp.hip) take over
 // for the hidden sizes it is built for.
 #include "common.h"
 
@@ -191,17 +191,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
             const int o = lane + 64 * c;
             if (o < d) h_out[(size_t)node * d + o] = x[c];
         }
-        if (h_split_out && split_layout == GHF_WLAYOUT_SPLIT3) {
-#pragma unroll
-            for (int c = 0; c < COMB_MAX_PER_LANE; ++c) {
-                const int o = lane + 64 * c;
-                if (o < d) {
-                    uint16_t pc[3];
-                    split3_pieces(x[c], pc);
-                    for (int pl = 0; pl < 3; ++pl) ((uint16_t*)h_split_out)[((size_t)node * 3 + pl) * d + o] = pc[pl];
-                }
-            }
-        } else if (h_split_out) {                          // SPLIT2H: the wave holds the whole row
+        if (h_split_out) {                                 // SPLIT2H: the wave holds the whole row
             float mx = 0.f;
 #pragma unroll
             for (int c = 0; c < COMB_MAX_PER_LANE; ++c)

@@ -1,7 +1,8 @@
 // message_hx.hip — K2+K3 with the fp32 contraction on the fp16 matrix pipe as three products of two-piece operands
-// (hidden 128).  The default kernel for d = 128.
+// (hidden 128).  Round 1's default for d = 128; message_bx.hip (block sums in registers, larger blocks) has taken over,
+// and this kernel stays selectable (GHF_KERNEL=hx) as the reference point it is measured against.
 //
-// Plan geometry, block sums in LDS, segment-sum scatter and fused tail are message_mfma.hip's (read its header first);
+// Plan geometry, block sums in LDS, segment-sum scatter and fused tail are message_pp.hip's (read its header first);
 // the producer / consumer wave roles are described below.  What is specific to this file is how a chunk's small GEMM
 // [rows, 2d] x [2d, d] is evaluated, and why:
 //
@@ -10,8 +11,8 @@
 //   * With 16-bit pieces the matrix pipe stops being the limit and the bytes a CU pulls in per chunk become it
 //     (tools/micro/l2stream.hip: ~33 TB/s chip-wide while the streamed footprint fits the 4 MiB L2s, ~16 TB/s at
 //     12 MiB, ~7 TB/s from HBM).  Per chunk that is one relation's [2d, d] weights plus ~34 gathered rows, so the
-//     weights' bytes decide: three bf16 pieces (message_sx.hip, exact, no scaling) are 6 bytes per weight and
-//     measured 5.9 ms; TWO fp16 pieces are 4 bytes — the size of the fp32 weights themselves — and 22 significand
+//     weights' bytes decide: three bf16 pieces (exact, no scaling; a round-1 kernel, since removed) are 6 bytes per
+//     weight and measured 5.9 ms; TWO fp16 pieces are 4 bytes — the size of the fp32 weights themselves — and 22 significand
 //     bits:
 //          x * 2^s = hi + lo + eps,   hi = fp16(x 2^s),  lo = fp16(x 2^s - hi),  |eps| <= 2^-22 |x 2^s|
 //     where the power of two 2^s (one per activation row, one per relation's weight matrix) lifts the largest
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
     // After a chunk's second phase its rows (acc) join the block sums.  All MTC tiles, no branch around memory
     // operations (see decode): rows of dead tiles have dummy targets.
     // Segment sum: a tile with a run of equal destinations is multiplied by S[i][k] = (head(k) == i) on the fp32 MFMA;
-    // then a plain LDS read-add-write through inline asm (see message_mfma.hip).  The block sums keep a wave's 32
+    // then a plain LDS read-add-write through inline asm (see message_pp.hip).  The block sums keep a wave's 32
     // columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column 32*tw + 16*t + c16; the tail undoes it), so a
     // lane's two values are adjacent and move with one 64-bit access.
     // (Interleaving these pieces with the next chunk's MFMAs was tried and measured the same: the stage period is set

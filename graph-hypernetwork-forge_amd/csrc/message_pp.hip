@@ -1,24 +1,33 @@
-// message_pp.hip — K2+K3, "ping-pong" schedule (hidden sizes 128 and 64).
+// message_pp.hip — K2+K3 in exact fp32 on the matrix cores, "ping-pong" schedule (hidden sizes 128 and 64).
 //
-// Same math, plan, LDS layout and results as message_mfma.hip (see its header for the geometry: a workgroup owns
-// BN destination nodes and their fp32 sums in LDS; a chunk = <= 48 rows of one relation = a small GEMM run as two
-// K-phases from an LDS A tile and register B fragments; segment-sum MFMA + plain LDS read-add-write into the sums;
-// fused tail).  What differs is WHO does WHAT between two barriers.
+// Replaces models/hypergnn.py:281-296 of the reference:
+//   out_v = (1/max(indeg_v,1)) * sum_{e=(u->v)} ( h_u W_msg[r_e] + bias[r_e] + h_v W_self[r_e] ),  h'_v = LayerNorm(ReLU(out_v + h_v))
+// with v_mfma_f32_16x16x4_f32 (an fp32 fma chain from 0): the d = 64 kernel, and at d = 128 the exact kernel the range
+// guard (ghf.h: ghf_set_range_flag) and GHF_KERNEL=pp route to; the default d = 128 kernel is message_bx.hip.
 //
-// In message_mfma.hip all 8 waves run the same program, so the two waves that share a SIMD reach their non-MFMA
-// segments (prefetch issue, waits, barrier, scatter) together and the SIMD's matrix pipe idles there: stamped 66 %
-// busy, 8.0 ms even with the scatter removed, against a 5.3 ms MFMA floor.
-// Here the 8 waves form two TEAMS of 4 (one wave per SIMD each; waves w and w+4 share a SIMD).  A wave owns 32
-// output columns (2 fragments), so one team covers all 128.  Teams take alternate chunks and alternate ROLES every
+// Geometry.  A workgroup owns BN consecutive destination nodes and keeps their fp32 sums [BN][D] in LDS for the whole
+// kernel: no global atomics, the tail is fused, every h' row is written once.  plan.hip has sorted the block's in-edges by
+// (relation, destination) and cut them into chunks of <= 48 rows of ONE relation; a chunk is a small GEMM
+// [rows, 2D] x [2D, D] — A row = [h_src | h_dst], gathered into an LDS tile; B = [W_msg[r]; W_self[r]] in MFMA fragment
+// order (GHF_WLAYOUT_FRAG16), streamed from L2 into registers — run as two K-phases of D.  A wave owns 32 output columns
+// and is the only writer of its strip of the block sums: fixed summation order, bitwise reproducible.
+// Adding a chunk's rows to the sums: rows are sorted by destination, so per 16-row tile one more MFMA product with the 0/1
+// matrix S[i][k] = (head(k) == i) (head = first row of k's run of equal destinations, from the plan) moves each run's sum
+// into its first row — exact — and the live rows, now of distinct destinations, are added by a plain LDS read-add-write
+// (ds_add_f32 measured ~110 cycles per wave instruction: more than the contraction).
+// LDS (D=128): sums (216+4)*512 B + 2 A tiles 48*512 B + row words = 162,176 B (1 workgroup/CU); (D=64): 81,280 B (2/CU).
+//
+// Schedule.  With all 8 waves on one program the two waves of a SIMD reach their non-MFMA segments (prefetch issue,
+// waits, barrier, scatter) together and the matrix pipe idles there (stamped 66 % busy).  Here the waves form two TEAMS
+// of 4 (one wave per SIMD each; waves w and w+4 share a SIMD); teams take alternate chunks and alternate ROLES every
 // barrier interval:
 //      interval g     team g&1      : MFMA   — one K-phase of its chunk, nothing but ds_read + v_mfma
 //                     the other team: PREP   — scatter of its finished chunk, LDS-DMA gather of its next A tile,
 //                                              B-fragment / index / descriptor loads, then s_waitcnt vmcnt(0)
 // so each SIMD always has one wave feeding the matrix pipe while its partner absorbs every memory latency.
-// Each team has its own A tile (the two tiles of the old double buffer), B fragments are loaded in PREP into the
-// registers the team's previous MFMA interval just released (no double buffering of B), and no global load is ever
-// issued inside an MFMA interval.  Scatters of the two teams never overlap in time (they are in different
-// intervals), and a team scatters its chunks in order, so the sums are still bitwise reproducible.
+// Each team has its own A tile, B fragments are loaded in PREP into the registers the team's previous MFMA interval
+// just released, and no global load is issued inside an MFMA interval.  Scatters of the two teams never overlap in time
+// and a team scatters its chunks in order, so the sums stay bitwise reproducible.
 #include "common.h"
 
 #include <stdlib.h>
@@ -42,7 +51,7 @@ __device__ __forceinline__ const T* at(const void* base, uint32_t byte_off) {
     return (const T*)((const char*)base + byte_off);
 }
 
-// Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals, as in message_mfma.hip
+// Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals
 #ifdef GHF_STAMPS
 __device__ unsigned long long ghf_pp_stamp_buf[8192 * 8 * 8];
 #define PP_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
 
     // Gather the (chunk, phase) A tile into this team's buffer, register-staged: the 16-byte loads are issued early
     // in PREP (stage_load) and written to LDS at its end (stage_commit), after the scatter has covered their latency.
-    // (LDS-DMA, used by message_mfma.hip where no MFMA runs during the issue, stamped ~450 cycles per instruction to
+    // (LDS-DMA, measured in a schedule where no MFMA runs during the issue, stamped ~450 cycles per instruction to
     // issue from a wave whose SIMD partner streams MFMAs: 2,700 of a 6,700-cycle PREP.)  The LDS image is the same:
     // 16-byte chunks XOR-swizzled by (row & 15) via the SOURCE address, rows linear.  Phase 1 also publishes the
     // chunk's row words: (byte offset of the row's target in the block sums) | run head.  Every instruction here
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(512, PpCfg<D>::WAVES_PER_SIMD) void message_pp_kern
                 for (int t = 0; t < NTW; ++t)
                     y[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, x[m][t][s], y[m][t], 0, 0, 0);
             }
-        // plain LDS read-add-write through inline asm (see message_mfma.hip), tile by tile: a run of equal
+        // plain LDS read-add-write through inline asm (see the header), tile by tile: a run of equal
         // destinations may continue into the next tile.  With two fragments per wave (D = 128) the block sums keep a
         // wave's 32 columns INTERLEAVED (LDS position 32*tw + 2*c16 + t holds column 32*tw + 16*t + c16; the tail
         // undoes it), so a lane's two values are adjacent and move with one 64-bit LDS access.
@@ -505,6 +514,17 @@ static int launch_pp_for(const MsgArgs& a, hipStream_t stream) {
     GHF_LAUNCH_CHECK();
     if (a.n_items > cdiv(a.rows, C::BN)) return launch_combine_split(a, stream);     // some block of the range is split
     return GHF_OK;
+}
+
+// split_chunks: a destination block with more chunks than this is cut into several work items (plan.hip).  A block of a
+// uniform graph at the BASELINE configs has ~65 chunks, so only real hubs are split.
+bool message_pp_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks) {
+    *split_chunks = 128;
+    switch (d) {
+        case 128: *block_nodes = PpCfg<128>::BN; *chunk_rows = 16 * PpCfg<128>::MTC; return true;
+        case 64:  *block_nodes = PpCfg<64>::BN;  *chunk_rows = 16 * PpCfg<64>::MTC;  return true;
+        default:  return false;
+    }
 }
 
 int launch_message_pp(const MsgArgs& a, hipStream_t stream) {

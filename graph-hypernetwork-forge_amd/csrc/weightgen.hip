@@ -78,14 +78,6 @@ __device__ __forceinline__ size_t frag16_index(int r, int kk, int o, int d) {
     return ((((size_t)r * NT + (o >> 4)) * NJ2 + (kk >> 4)) * 64 + (((kk & 15) >> 2) << 4) + (o & 15)) * 4 + (kk & 3);
 }
 
-// GHF_WLAYOUT_SPLIT3: x = p0 + p1 + p2 exactly, p_i = the i-th group of 8 significand bits as a bf16 (truncation);
-// element (r, kk, o) of the combined matrix lives, piece by piece, at
-//   Wsplit[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8]   (bf16 units), kk in [0, 2d).
-__device__ __forceinline__ size_t split3_index(int r, int kk, int o, int d) {           // of piece 0; pieces are 512 apart
-    const int NT = d >> 4, NKS = d >> 4;
-    return ((((size_t)r * NT + (o >> 4)) * NKS + (kk >> 5)) * 3 * 64 + (((kk & 31) >> 3) << 4) + (o & 15)) * 8 + (kk & 7);
-}
-
 // Vector-ALU last layer: one wave per output element n (lanes stride K), looping relations.
 // grid (ceil(n_out / 4)), block 256 (4 waves).
 __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restrict__ z /* [R,Hl] */,
@@ -116,12 +108,6 @@ __global__ __launch_bounds__(256) void wg_out_simple_kernel(const float* __restr
             const float v = (s + bn) * scale;
             if (head == 2 || layout == GHF_WLAYOUT_NATURAL) {
                 out[(size_t)r * rstride + n] = v;
-            } else if (layout == GHF_WLAYOUT_SPLIT3) {
-                const int i = n / d_out, o = n - i * d_out;
-                uint16_t pc[3];
-                split3_pieces(v, pc);
-                uint16_t* dst = (uint16_t*)out + split3_index(r, head * d_in + i, o, d_out);
-                for (int pl = 0; pl < 3; ++pl) dst[pl * 512] = pc[pl];
             } else {
                 const int i = n / d_out, o = n - i * d_out;
                 out[frag16_index(r, head * d_in + i, o, d_out)] = v;
@@ -185,23 +171,7 @@ __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restric
         }
         // D layout: lane holds rows 4q + reg (reg 0..3), column c16 (= relation rc)
         if (!b_ok) continue;
-        if (LAYOUT == GHF_WLAYOUT_SPLIT3) {
-            // rows 4q..4q+3 = four consecutive kk of one lane slot: 8 bytes per piece
-            uint16_t pc[4][3];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int n = (16 * it + 4 * q + s) * d + o;
-                split3_pieces((acc[s] + b3[n]) * scale, pc[s]);
-            }
-            const int kk0 = head * d + 16 * it + 4 * q;   // kk & 3 == 0
-            uint16_t* dst = (uint16_t*)out + split3_index(rc, kk0, o, d);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const uint2 v = make_uint2((uint32_t)pc[0][pl] | ((uint32_t)pc[1][pl] << 16),
-                                           (uint32_t)pc[2][pl] | ((uint32_t)pc[3][pl] << 16));
-                *(uint2*)(dst + pl * 512) = v;
-            }
-        } else if (LAYOUT == GHF_WLAYOUT_FRAG16) {
+        if (LAYOUT == GHF_WLAYOUT_FRAG16) {
             f32x4 v;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -347,17 +317,13 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
     GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
     GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
     GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
-    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT3 ||
-                    layout == GHF_WLAYOUT_SPLIT2H, "weightgen: bad layout %d", layout);
+    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT2H, "weightgen: bad layout %d", layout);
     if (layout == GHF_WLAYOUT_SPLIT2H)
         GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && (size_t)2 * d_in * d_out * 4 <= 128 * 1024 && W_self == nullptr,
                     "weightgen: SPLIT2H needs d_in == d_out, d %% 32 == 0, d <= 128 and W_self == NULL");
     if (layout == GHF_WLAYOUT_FRAG16)
         GHF_REQUIRE(d_in == d_out && (d_in % 16) == 0 && W_self == nullptr,
                     "weightgen: FRAG16 needs d_in == d_out, d %% 16 == 0 and W_self == NULL");
-    else if (layout == GHF_WLAYOUT_SPLIT3)
-        GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && W_self == nullptr,
-                    "weightgen: SPLIT3 needs d_in == d_out, d %% 32 == 0 and W_self == NULL");
     else if (layout == GHF_WLAYOUT_NATURAL)
         GHF_REQUIRE(W_self != nullptr, "weightgen: NATURAL layout needs W_self");
 
@@ -388,11 +354,7 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
         const int klayout = nat ? GHF_WLAYOUT_NATURAL : layout;
         const bool mfma_ok = head != 2 && (Hl % 16) == 0 &&
                              ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
-        if (mfma_ok && layout == GHF_WLAYOUT_SPLIT3) {
-            const int mtiles = n_mat / 16;
-            wg_out_mfma_kernel<GHF_WLAYOUT_SPLIT3><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
-        } else if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
+        if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
                 z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);

@@ -47,8 +47,7 @@ extern "C" {
 /* Weight layouts produced by ghf_weightgen_fwd and consumed by ghf_message_layer_fwd */
 #define GHF_WLAYOUT_NATURAL 0 /* W_msg[R][d_in][d_out], W_self[R][d_in][d_out] row-major, as the reference returns them */
 #define GHF_WLAYOUT_FRAG16  1 /* MFMA 16x16x4 B-fragment order: Wfrag[R][d/16][2d/16][64 lanes][4] */
-#define GHF_WLAYOUT_SPLIT3  2 /* bf16 MFMA 16x16x32 B-fragment order, every fp32 weight cut exactly into 3 bf16 pieces:
-                                 Wsplit[R][d/16][2d/32][3 pieces][64 lanes][8] bf16 = 6 bytes per weight */
+/*      (2: three exact bf16 pieces — retired with its kernel in ABI 10; the number is not reused) */
 #define GHF_WLAYOUT_SPLIT2H 3 /* fp16 MFMA 16x16x32 B-fragment order, every weight of relation r scaled by a power of two
                                  2^s(r) and cut into 2 fp16 pieces: Wh[R][d/16][2d/32][2 pieces][64 lanes][8] fp16 = 4 bytes
                                  per weight, followed by float 2^-s(r) [R] */
@@ -140,7 +139,7 @@ int ghf_input_proj_fwd(const float* x, const float* W_in, const float* b_in,
  * blk_item_off[ceil((row0+rows)/BN)] - item0 (host copies of two plan words); partial: scratch of
  * status[2]*BN*d floats for the split blocks (may be NULL when status[2] == 0).
  * h_split: the rows of h cut into pieces by ghf_split_rows (or by a previous call's h_split_out); required when
- * wlayout is SPLIT3 or SPLIT2H, ignored otherwise.  h_split_out (optional, those layouts only, not with
+ * wlayout is SPLIT2H, ignored otherwise.  h_split_out (optional, that layout only, not with
  * GHF_FLAG_NO_TAIL): receives the split form of the h_out rows written by this call, for the next layer.
  * agg_out (optional, not with GHF_FLAG_NO_TAIL; ghf_message_side_output_supported): also receives, for the rows written,
  * the aggregate before the tail — what GHF_FLAG_NO_TAIL would have written to h_out — which a training forward keeps for
@@ -160,7 +159,6 @@ int ghf_message_layer_fwd(const float* h /* [N,d] */, const void* h_split /* ghf
 
 /* Rows [row0, row0+rows) of h [N,d] in the form the message kernel of `wlayout` gathers (the split is done once per
  * row here instead of once per edge there); h_split holds ghf_split_rows_bytes(N, d, wlayout) bytes:
- *   SPLIT3 : h_split[v][3 pieces][d] bf16 — x = p0 + p1 + p2 exactly (8 + 8 + 8 significand bits, by truncation);
  *   SPLIT2H: h_split[v][2 pieces][d] fp16 — x 2^s(v) = hi + lo (22 significand bits), 2^s(v) lifting the row's largest
  *            magnitude into [2^13, 2^14) — followed by float 2^-s(v) [N].
  * Other layouts gather h itself (ghf_split_rows_bytes == 0).  d % 4 == 0. */

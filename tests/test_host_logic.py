@@ -40,12 +40,12 @@ def test_abi_argument_validation_without_a_gpu():
         os.environ["GHF_KERNEL"] = "pp"
         assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
         assert (bn.value, wl.value, cr.value, sc.value) == (216, 1, 48, 128)  # fp32 MFMA contraction
-        os.environ["GHF_KERNEL"] = "sx"
+        os.environ["GHF_KERNEL"] = "sx"                                        # (a retired name: the default)
         assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
-        assert (bn.value, wl.value, cr.value, sc.value) == (162, 2, 48, 128)  # three bf16 pieces
+        assert (bn.value, wl.value) == (216, 1)
     finally:
         del os.environ["GHF_KERNEL"]
-    assert lib.ghf_split_rows_bytes(10, 128, 3) == 10 * 128 * 4 + 40 and lib.ghf_split_rows_bytes(10, 128, 2) == 10 * 128 * 6
+    assert lib.ghf_split_rows_bytes(10, 128, 3) == 10 * 128 * 4 + 40 and lib.ghf_split_rows_bytes(10, 128, 2) == 0
     assert lib.ghf_split_rows_bytes(10, 128, 1) == 0
     assert lib.ghf_weights_bytes(4, 128, 128, 3) == 4 * 2 * 128 * 128 * 4 + 16 and lib.ghf_weights_bytes(4, 8, 24, 0) == 4 * 8 * 24 * 4
     assert lib.ghf_message_config(64, ref(bn), ref(wl), ref(cr), ref(sc)) == 0 and (bn.value, cr.value) == (216, 48)
