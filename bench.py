@@ -59,7 +59,7 @@ def layer_flops(N, E, R, d):
 
 def kern_name(plan, d):
     from graph_hypernetwork_forge_amd import _native
-    return {_native.WLAYOUT_SPLIT2H: "message_bx_kernel" if plan.block_nodes == 384 else "message_hx_kernel"}.get(
+    return {_native.WLAYOUT_SPLIT2H: "message_hx_kernel" if plan.block_nodes == 216 else "message_bx_kernel"}.get(
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
@@ -324,7 +324,7 @@ def main():
             traffic = sum((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for v in parts)
             traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2; per-launch means" + \
                           (", summed over the layer's kernels)" if len(parts) > 1 else ")")
-        kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<128>"}.get(
+        kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<%d>" % d}.get(
             plan.wlayout, "message_pp_kernel<%d>" % d if plan.block_nodes > 1 else "message_generic_kernel")
         if wide:
             kern = "edge_transform_kernel + segment_tail_kernel<%d> (one layer)" % (d // 64)

@@ -40,6 +40,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <class T>
@@ -146,6 +147,16 @@ template <> struct BxCfg<128> {
     static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
     static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 32;
 };
+// hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk decides:
+// long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block (two units per helper
+// lane) so that C2's 100 k nodes still make 391 workgroups for 256 CUs
+template <> struct BxCfg<64> {
+    static constexpr int U = 2, UW = 32, CR = 112;
+    static constexpr int BN = 4 * U * UW;          // 256 lanes x U units x UW positions / 64
+    static constexpr int MTC = (CR + 15) / 16;
+    static constexpr bool YT = false;
+    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 32;
+};
 
 struct BxChunk { int r; int e0; int rows; };
 
@@ -178,10 +189,17 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr int MSTR = 4 * CRP + 4;         // words per chunk descriptor: sc_u, sc_v, src id, dst id [CRP each], rows
     constexpr int NU = D / UW;                // units per node
     constexpr int NPW = BN / TW;              // nodes per helper wave
-    constexpr int RBN = CR / 4;               // 4-row blocks (= 1 KiB DMA pieces) per plane
+    constexpr int RPP = 1024 / ROWB;          // rows per 1 KiB DMA piece of a plane (4 at d = 128, 8 at d = 64)
+    constexpr int LPR = 64 / RPP;             // lanes (16-byte granules) per row of a piece
+    constexpr int RBN = CR / RPP;             // pieces per plane
+    constexpr int CPL = D / 16;               // tail: columns per lane (16 lanes per row)
     constexpr int RBW = (RBN + TW - 1) / TW;  // pieces per helper wave and plane
     constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
-    static_assert(NTW == 2 && CR % 4 == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
+    static_assert((NTW == 2 || NTW == 1) && CR % RPP == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
+    // the XOR key of a row's 16-byte granules in an A tile: 16 granules per row at d = 128 (key = row mod 16); 8 at d = 64, where
+    // two rows share a 256-byte bank line, so the key is (row / 2) mod 8 — either way the 16 rows of a fragment read hit every
+    // bank once
+    auto akey = [](int row) -> int { return D == 128 ? (row & 15) : ((row >> 1) & 7); };
     // P0[2] source-row tiles, P1[2] destination-row tiles; a chunk's staged rows Y overwrite its own P1 tile — or, where
     // five tiles fit (YT: rows per chunk <= 60), have a tile of their own: then neither DMA waits for the fold
     constexpr bool YT = C::YT;
@@ -225,13 +243,14 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     // ---- fused tail from LDS (both roles; the helpers dump their registers first, NPW / 2 nodes per wave at a time) ----
     // dump row v = (NPW/2) * hw + i  <->  node NPW * hw + (NPW/2) * half + i   (helper lanes 32*half .. 32*half + 31)
     constexpr int HN = BN / 2, HPW = NPW / 2;
-    // 16 lanes per row (a wave works on four rows at a time), eight adjacent columns per lane: every load and store is
+    // 16 lanes per row (a wave works on four rows at a time), CPL = d / 16 adjacent columns per lane: every load and store is
     // 16 bytes per lane, and a row reduction is four DPP steps inside its 16-lane row — for four rows at once.  (One wave
     // per row, two columns per lane, took 1,800 cycles per row: ~110 dependent instructions, 2- and 4-byte stores.)
-    auto tail_half = [&](int half, auto gb_c) {          // gb_c: four-row groups in flight per wave
+    auto tail_half = [&](int half, auto gb_c) __attribute__((always_inline)) {          // gb_c: four-row groups in flight per wave
         if (GHF_BXEXP & 32) return;
         const float* acc_lds = (const float*)smem;       // dump rows, natural column order
-        const int sub = lane >> 4, c0 = 8 * (lane & 15);
+        const int sub = lane >> 4, c0 = CPL * (lane & 15);
+        constexpr int NV = CPL / 4;                      // 16-byte pieces per lane and row
         auto node_of = [&](int v) -> int { return (v / HPW) * NPW + half * HPW + (v % HPW); };   // block-local node of dump row v
         auto row_sum = [&](float v) -> float {           // over the 16 lanes of a row, result in each of them
             v += dpp_take<0xB1, 0xF>(v);
@@ -252,22 +271,21 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             float* __restrict__ ps = partial + (size_t)slot * BN * D;
             for (int g = w; g < NG; g += NWV) {
                 const int v = 4 * g + sub;
-                const f32x4 a0 = *(const f32x4*)(acc_lds + v * D + c0), a1 = *(const f32x4*)(acc_lds + v * D + c0 + 4);
                 float* __restrict__ o = ps + (size_t)node_of(v) * D + c0;
-                *(f32x4*)o = a0;
-                *(f32x4*)(o + 4) = a1;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) *(f32x4*)(o + 4 * i) = *(const f32x4*)(acc_lds + v * D + c0 + 4 * i);
             }
             return;
         }
-        float gm[8], bt[8];
+        float gm[CPL], bt[CPL];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < CPL; ++c) {
             gm[c] = no_tail ? 1.f : gamma[c0 + c];
             bt[c] = no_tail ? 0.f : beta[c0 + c];
         }
         constexpr int GB = decltype(gb_c)::value;
         for (int g0 = w; g0 < NG; g0 += NWV * GB) {
-            f32x4 x[GB][2];
+            f32x4 x[GB][NV];
             float inv[GB];
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
@@ -277,8 +295,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 const int deg = indeg[node];
                 inv[gb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
                 const float* __restrict__ hp = h + (size_t)node * D + c0;
-                x[gb][0] = no_tail ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)hp;
-                x[gb][1] = no_tail ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) x[gb][i] = no_tail ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4 * i);
             }
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
@@ -286,60 +304,62 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 const int v = 4 * (g < NG ? g : NG - 1) + sub;
                 const int nl = node_of(v);
                 const bool live = g < NG && nl < nrows;
-                const f32x4 a0 = *(const f32x4*)(acc_lds + v * D + c0), a1 = *(const f32x4*)(acc_lds + v * D + c0 + 4);
+                f32x4 a[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) a[i] = *(const f32x4*)(acc_lds + v * D + c0 + 4 * i);
                 if (agg_out && live) {                   // side output: the mean before the tail (what the backward keeps)
                     float* __restrict__ o = agg_out + (size_t)(node0 + nl) * D + c0;
-                    *(f32x4*)o = a0 * inv[gb];
-                    *(f32x4*)(o + 4) = a1 * inv[gb];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) *(f32x4*)(o + 4 * i) = a[i] * inv[gb];
                 }
-                float y[8];
+                float y[CPL];
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float a = (c < 4 ? a0[c] : a1[c - 4]) * inv[gb];
-                    y[c] = no_tail ? a : fmaxf(a + x[gb][c >> 2][c & 3], 0.f);
+                for (int c = 0; c < CPL; ++c) {
+                    const float av = a[c >> 2][c & 3] * inv[gb];
+                    y[c] = no_tail ? av : fmaxf(av + x[gb][c >> 2][c & 3], 0.f);
                     s += y[c];
                 }
                 if (!no_tail) {
                     const float mean = row_sum(s) * (1.0f / D);
                     float var = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) { const float t = y[c] - mean; var += t * t; }
+                    for (int c = 0; c < CPL; ++c) { const float t = y[c] - mean; var += t * t; }
                     const float rstd = 1.0f / sqrtf(row_sum(var) * (1.0f / D) + eps);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) y[c] = (y[c] - mean) * rstd * gm[c] + bt[c];
+                    for (int c = 0; c < CPL; ++c) y[c] = (y[c] - mean) * rstd * gm[c] + bt[c];
                 }
                 float up = 1.f;
                 if (h_split_out) {                       // the same row cut into fp16 pieces, for the next layer's gathers
                     float mx = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fabsf(y[c]));
+                    for (int c = 0; c < CPL; ++c) mx = fmaxf(mx, fabsf(y[c]));
                     const int sh = split2h_shift(row_max(mx));
                     up = pow2f(sh);
                     if ((lane & 15) == 0 && live) *(float*)((char*)h_split_out + (size_t)hsc_off + (size_t)(node0 + nl) * 4) = pow2f(-sh);
                 }
                 if (live) {
                     float* __restrict__ o = h_out + (size_t)(node0 + nl) * D + c0;
-                    *(f32x4*)o = (f32x4){y[0], y[1], y[2], y[3]};
-                    *(f32x4*)(o + 4) = (f32x4){y[4], y[5], y[6], y[7]};
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) *(f32x4*)(o + 4 * i) = (f32x4){y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3]};
                     if (h_split_out) {
                         _Float16* __restrict__ sp = (_Float16*)h_split_out + (size_t)(node0 + nl) * (NPL * D) + c0;
-                        f16x8 hi8, lo8;
+                        _Float16 hi[CPL], lo[CPL];
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            _Float16 hi, lo;
-                            split2h(y[c] * up, hi, lo);
-                            hi8[c] = hi;
-                            lo8[c] = lo;
+                        for (int c = 0; c < CPL; ++c) split2h(y[c] * up, hi[c], lo[c]);
+                        if constexpr (CPL == 8) {
+                            *(f16x8*)sp = (f16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+                            *(f16x8*)(sp + D) = (f16x8){lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+                        } else {
+                            *(f16x4*)sp = (f16x4){hi[0], hi[1], hi[2], hi[3]};
+                            *(f16x4*)(sp + D) = (f16x4){lo[0], lo[1], lo[2], lo[3]};
                         }
-                        *(f16x8*)sp = hi8;
-                        *(f16x8*)(sp + D) = lo8;
                     }
                 }
                 if (h_split_out) {                       // range guard (common.h): rows with many entries far below their largest
                     int tiny = 0, nz = 0;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) { tiny += range_tiny(y[c] * up); nz += y[c] != 0.f; }
+                    for (int c = 0; c < CPL; ++c) { tiny += range_tiny(y[c] * up); nz += y[c] != 0.f; }
                     if (__ballot(tiny != 0)) {           // (rare)
                         tiny = (int)row_sum((float)tiny);
                         nz = (int)row_sum((float)nz);
@@ -387,8 +407,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             if (hw == 0 && ln == 0) lds_st_b32(m + 4 * (4 * CRP), c.rows);
         };
-        // ---- LDS-DMA gather of one A tile: piece = rows 4*rb .. 4*rb+3 of one plane (1 KiB), 16 lanes per row; the
-        // granules of a row are XOR-swizzled by (row & 15) as the consumers' fragment reads expect (message_hx.hip) ----
+        // ---- LDS-DMA gather of one A tile: piece = RPP consecutive rows of one plane (1 KiB), LPR lanes per row; the
+        // granules of a row are XOR-swizzled by akey(row), as the consumers' fragment reads expect ----
         auto dma_tile = [&](unsigned tile_off, int j, int which /*2: src ids, 3: dst ids*/, int rows, bool nt, int lane) {
             const unsigned ids = lds0 + meta_off(j) + 4 * (which * CRP);
             if (GHF_BXEXP & 2) return;
@@ -396,13 +416,13 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             unsigned ia[6];
             int id[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ia[i] = ids + 4 * (4 * (hw + TW * (i < RBW ? i : 0)) + (lane >> 4));
+            for (int i = 0; i < 6; ++i) ia[i] = ids + 4 * (RPP * (hw + TW * (i < RBW ? i : 0)) + lane / LPR);
             lds_ld_b32_x6(ia, id);
 #pragma unroll
             for (int i = 0; i < RBW; ++i) {
-                const int rb = hw + TW * i, row = 4 * rb + (lane >> 4);
-                if (4 * rb >= rows) continue;               // (uniform) a piece without live rows is not issued
-                const int g = (lane & 15) ^ (row & 15);
+                const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
+                if (RPP * rb >= rows) continue;             // (uniform) a piece without live rows is not issued
+                const int g = (lane & (LPR - 1)) ^ akey(row);
                 // dead rows: an offset past the end of the buffer (zeros, no memory access)
                 const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : 0x7FFFFF00;
                 // a piece past the tile (RBN not a multiple of 4 waves) lands in a scratch KiB
@@ -450,11 +470,13 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 while (mask) {
                     const int r0 = pass * 64 + (int)__builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const unsigned pa = Y + (unsigned)r0 * (D * 4) + (unsigned)(((2 * lane) ^ (((r0 >> 2) & 1) << 5)) * 4);
-                    const unsigned pb = Y + (unsigned)(r0 + 1) * (D * 4) + (unsigned)(((2 * lane) ^ ((((r0 + 1) >> 2) & 1) << 5)) * 4);
-                    f32x2 x, y;
-                    lds_ld_b64_x2(pa, pb, x, y);
-                    lds_st_b64(pb, x + y);
+                    if (2 * lane < D) {                     // two positions per lane
+                        const unsigned pa = Y + (unsigned)r0 * (D * 4) + (unsigned)(((2 * lane) ^ (((r0 >> 2) & 1) << 5)) * 4);
+                        const unsigned pb = Y + (unsigned)(r0 + 1) * (D * 4) + (unsigned)(((2 * lane) ^ ((((r0 + 1) >> 2) & 1) << 5)) * 4);
+                        f32x2 x, y;
+                        lds_ld_b64_x2(pa, pb, x, y);
+                        lds_st_b64(pb, x + y);
+                    }
                 }
             }
             // 2. every owner lane: the staged row of its node, if any; then the table is free for the next chunk
@@ -644,10 +666,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 for (int k = 0; k < U; ++k) {
                     const int u = U * lane + k, nl = u / NU, part = u % NU;
                     const unsigned a = lds0 + (unsigned)(hw * HPW + (nl - half * HPW)) * (D * 4) + (unsigned)part * (UW * 4);
-                    // position 2x + t of a 32-position group is column 16t + x of it (the consumers' C layout): the dump is
-                    // in column order
+                    // d = 128: position 2x + t of a 32-position group is column 16t + x of it (a consumer wave's two fragments,
+                    // interleaved); d = 64: positions are columns.  The dump is in column order
                     static_assert(UW == 32, "the dump's position -> column permutation is per 32-position unit");
-                    auto cv = [&](int c) -> float { return sums[k][2 * (c & 15) + (c >> 4)]; };
+                    auto cv = [&](int c) -> float { return NTW == 2 ? sums[k][2 * (c & 15) + (c >> 4)] : sums[k][c]; };
 #pragma unroll
                     for (int i = 0; i < UW / 4; ++i)
                         lds_st_b128(a + 16 * i, (f32x4){cv(4 * i), cv(4 * i + 1), cv(4 * i + 2), cv(4 * i + 3)});
@@ -686,8 +708,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         const int arow = c16 * ROWB;
         // One instance per number of live row tiles: no branch, no LDS read and no zeroing for dead tiles inside the loop
         // (a uniform branch per (k-step, tile) position cost the MFMA stream a fetch bubble each)
+        // (always_inline: with two call sites and little work per instance — d = 64 — hipcc otherwise makes the stage a real
+        // function, called through s_swappc with its captures in scratch: 10x the time)
         auto compute_stage = [&](auto mt_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
-                                 const float (&bias_v)[NTW]) {
+                                 const float (&bias_v)[NTW]) __attribute__((always_inline)) {
             constexpr int MT = decltype(mt_c)::value;
             f32x4 part[MTC][NTW];
 #pragma unroll
@@ -701,7 +725,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             constexpr int AD = GHF_BX_AD;
             i32x4 a[AD + 1][NPL];
             auto lda = [&](int j, int m, i32x4 (&dst)[NPL]) {
-                const char* src = Abuf + arow + (((4 * j + q) ^ c16) << 4) + m * 16 * ROWB;
+                const char* src = Abuf + arow + (((4 * j + q) ^ akey(c16)) << 4) + m * 16 * ROWB;     // akey(16 m + c16) = akey(c16)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) dst[pl] = *(const i32x4*)(src + pl * PLANE);
             };
@@ -760,7 +784,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         };
         auto stage_for = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
-                             const float (&bias_v)[NTW]) {
+                             const float (&bias_v)[NTW]) __attribute__((always_inline)) {
             // three instances: all tiles, one fewer, two fewer (shorter chunks — 7 % at C3 — run the last one: their dead
             // tiles cost MFMAs on stale rows that are never written)
             static_assert(MTC >= 3, "three compute_stage instances");
@@ -768,9 +792,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
             else compute_stage(std::integral_constant<int, MTC - 2>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
         };
-        // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1)
-        const unsigned yoff = (unsigned)(4 * q) * (D * 4) + (unsigned)(((32 * tw + 2 * c16) ^ ((q & 1) << 5)) * 4);
-        auto write_rows = [&](int mt, unsigned ytile) {
+        // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1) — with one
+        // fragment per wave (d = 64), position 16tw + c16
+        const unsigned yoff = (unsigned)(4 * q) * (D * 4) + (unsigned)((((NTW == 2 ? 32 * tw + 2 * c16 : 16 * tw + c16)) ^ ((q & 1) << 5)) * 4);
+        auto write_rows = [&](int mt, unsigned ytile) __attribute__((always_inline)) {
             const unsigned ybase = lds0 + ytile + yoff;
 #pragma unroll
             for (int m = 0; m < MTC; ++m) {
@@ -778,9 +803,13 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 // the last tile's rows past CR do not exist in Y (the table follows it)
                 if (16 * m + 16 > CR && 16 * m + 4 * q >= CR) continue;
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ybase), "v"((f32x2){acc[m][0][s], acc[m][1][s]}),
-                                 "n"((16 * m + s) * (D * 4)) : "memory");
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (NTW == 2)
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ybase), "v"((f32x2){acc[m][0][s], acc[m][NTW - 1][s]}),
+                                     "n"((16 * m + s) * (D * 4)) : "memory");
+                    else
+                        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ybase), "v"(acc[m][0][s]), "n"((16 * m + s) * (D * 4)) : "memory");
+                }
             }
         };
 
@@ -892,17 +921,20 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
 }
 
 bool message_bx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks) {
-    if (d != 128) return false;
-    *block_nodes = BxCfg<128>::BN;
-    *chunk_rows = BxCfg<128>::CR;
+    if (d != 128 && d != 64) return false;
+    *block_nodes = d == 128 ? BxCfg<128>::BN : BxCfg<64>::BN;
+    *chunk_rows = d == 128 ? BxCfg<128>::CR : BxCfg<64>::CR;
     *split_chunks = 128;
     return true;
 }
 
-bool message_bx_owns(int d, int block_nodes) { return d == 128 && block_nodes == BxCfg<128>::BN; }
+bool message_bx_owns(int d, int block_nodes) {
+    return (d == 128 && block_nodes == BxCfg<128>::BN) || (d == 64 && block_nodes == BxCfg<64>::BN);
+}
 
 int launch_message_bx(const MsgArgs& a, hipStream_t stream) {
     if (a.d == 128) return launch_bx_for<128>(a, stream);
+    if (a.d == 64) return launch_bx_for<64>(a, stream);
     return set_err(GHF_EUNSUPPORTED, "message(bx): no kernel for d=%d", a.d);
 }
 

@@ -60,6 +60,11 @@ class RsPlan:
 RS_TILE = 128
 RS_HUB_ROWS = 4096           # a destination with more rows than this is summed in chunks of this many by whole workgroups
 SRC_MASK = 0x0FFFFFFF
+# d = 64: the two-fp16-piece kernel (message_bx<64>) is 1.4x the exact fp32-MFMA kernel per edge, but its forward ends with the
+# range guard's read of a device word (ghf.h: ghf_set_range_flag) — a host sync.  A forward of a few hundred microseconds is
+# bound by the host's launches, which that sync stops from running ahead: at BASELINE config 2 (1 M edges) the kernel went
+# 0.237 -> 0.207 ms and the forward 0.67 -> 0.81 ms.  Below this many edges the exact kernel (no guard) is the default.
+D64_PIECES_MIN_EDGES = 4_000_000
 
 
 def exact_plan(plan: "GraphPlan", d: int) -> "GraphPlan":
@@ -185,6 +190,9 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
         bn, wl, cr, sc = _native.exact_config(d)
     else:
         bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else _native.message_config(d)
+        if (d == 64 and wl == _native.WLAYOUT_SPLIT2H and not os.environ.get("GHF_KERNEL")
+                and edge_index.size(1) < D64_PIECES_MIN_EDGES):
+            bn, wl, cr, sc = _native.exact_config(d)         # small graph: see D64_PIECES_MIN_EDGES
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range

@@ -39,7 +39,7 @@ def test_native_library_is_loaded():
     assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
     assert _native.message_config(128) == (384, _native.WLAYOUT_SPLIT2H, 76, 128)
-    assert _native.message_config(64) == (216, _native.WLAYOUT_FRAG16, 48, 128)
+    assert _native.message_config(64) == (256, _native.WLAYOUT_SPLIT2H, 112, 128)
     assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
     try:
         os.environ["GHF_KERNEL"] = "hx"
@@ -260,6 +260,12 @@ def _pack_weights(plan, Wm, Ws):
     return t(Wm), t(Ws)
 
 
+def _skip_unless_kernel_exists(kernel, d):
+    """d = 128: all three kernels; d = 64: bx and pp; other sizes have one kernel (run once, under "bx")."""
+    if kernel not in {128: ("hx", "bx", "pp"), 64: ("bx", "pp")}.get(d, ("bx",)):
+        pytest.skip(f"no {kernel} kernel for d = {d}")
+
+
 @pytest.fixture(params=["hx", "bx", "pp"])
 def kernel(request, monkeypatch):
     """The d = 128 message kernels: two fp16 pieces with the block sums in registers (bx, the default) or in LDS (hx), and
@@ -378,8 +384,7 @@ def _to_frag16(Wm, Ws):
 ])
 @pytest.mark.parametrize("no_tail", [False, True])
 def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail, kernel):
-    if kernel != "hx" and d != 128:
-        pytest.skip("only d = 128 has several contractions")
+    _skip_unless_kernel_exists(kernel, d)
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=1000 + d + R, kind=kind)
     plan = build_plan(torch.from_numpy(ei).to(DEV), torch.from_numpy(rel).to(DEV), [""] * R, N, d, DEV)
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
@@ -403,8 +408,7 @@ def test_message_layer_matches_oracle(d, N, E, R, kind, no_tail, kernel):
 def test_split_hub_blocks_match_oracle(d, kernel):
     """Power-law in-degrees: blocks with more chunks than split_chunks are cut into work items whose partial sums a
     second kernel combines in item order (ghf.h: item_tab) — same result, still bitwise reproducible."""
-    if kernel != "hx" and d != 128:
-        pytest.skip("only d = 128 has several contractions")
+    _skip_unless_kernel_exists(kernel, d)
     N, E, R = 6000, 150000, 8
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=4242, kind="powerlaw")
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
@@ -472,11 +476,15 @@ def test_side_output_and_zero_half_flags(N, E, R, kind):
 
 
 @pytest.mark.parametrize("d,N,E,R,kind", [(20, 300, 2500, 5, "powerlaw"), (128, 1200, 9000, 6, "uniform"),
-                                          (128, 500, 6000, 3, "powerlaw")])
-def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind):
+                                          (128, 500, 6000, 3, "powerlaw"), (64, 1500, 14000, 6, "uniform"),
+                                          (64, 700, 9000, 3, "powerlaw")])
+def test_message_layer_backward_matches_autograd_of_the_oracle(d, N, E, R, kind, monkeypatch):
     """Gradients of one layer with respect to h, W_msg, W_self, bias, gamma, beta: HIP backward (autograd.py) against
-    torch.autograd through the oracle's restatement of the reference ops."""
+    torch.autograd through the oracle's restatement of the reference ops.  (d = 64 on the two-piece kernel, which graphs of
+    this size do not take by default.)"""
     from graph_hypernetwork_forge_amd.autograd import MessageLayerFn, build_train_plan
+    if d == 64:
+        monkeypatch.setenv("GHF_KERNEL", "bx")
     ei, rel, h, Wm, Ws, b, gamma, beta = _layer_inputs(N, E, R, d, seed=300 + d + R, kind=kind)
     th = torch.from_numpy
     dev = lambda a: th(a).to(DEV).requires_grad_(True)                                      # noqa: E731
@@ -1112,8 +1120,11 @@ def test_relation_order_does_not_matter():
 
 # ---- BASELINE config 3 at full size: size-independent properties + sampled rows vs the oracle --
 
-def test_full_size_c3_layer_properties(kernel):
-    N, E, R, d = 1_000_000, 10_000_000, 64, 128
+@pytest.mark.parametrize("N,E,R,d", [(1_000_000, 10_000_000, 64, 128), (500_000, 5_000_000, 32, 64)])
+def test_full_size_c3_layer_properties(N, E, R, d, kernel):
+    """BASELINE config 3, and config 2's shape grown to where hidden 64 takes the two-piece kernel by default
+    (plan.D64_PIECES_MIN_EDGES)."""
+    _skip_unless_kernel_exists(kernel, d)
     ei, rel = synth.make_graph_arrays(N, E, R, seed=1003)
     g = torch.Generator(device="cpu").manual_seed(1)
     h = torch.randn(N, d, generator=g)
@@ -1130,7 +1141,7 @@ def test_full_size_c3_layer_properties(kernel):
     _native.message_layer_fwd(*args, out1)
     _native.message_layer_fwd(*args, out2)
     torch.cuda.synchronize()
-    assert torch.equal(out1, out2), "d=128 kernel must be bitwise reproducible"
+    assert torch.equal(out1, out2), "the block kernels must be bitwise reproducible"
     assert torch.isfinite(out1).all()
     # LayerNorm rows: zero mean, unit (biased) variance
     assert out1.mean(dim=1).abs().max().item() < 1e-4
@@ -1147,7 +1158,19 @@ def test_full_size_c3_layer_properties(kernel):
     th = torch.from_numpy
     ref = O.message_passing_factorised(h, th(sub_ei), th(sub_rel), th(Wm), th(Ws), th(b))
     ref = O.layer_tail(ref, h, th(gamma), th(beta))[rows]
-    assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), "sampled rows of the 10M-edge layer")
+    assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), f"sampled rows of the {E // 1_000_000}M-edge layer")
+
+
+def test_hidden_64_default_kernel_follows_the_graph_size(monkeypatch):
+    """plan.D64_PIECES_MIN_EDGES: small graphs keep the exact kernel (no range-guard sync), large ones take two fp16 pieces."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    monkeypatch.delenv("GHF_KERNEL", raising=False)
+    ei, rel = synth.make_graph_arrays(3000, 20000, 5, seed=3)
+    t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
+    assert build_plan(t(ei), t(rel), [""] * 5, 3000, 64, DEV).wlayout == _native.WLAYOUT_FRAG16
+    monkeypatch.setattr(plan_mod, "D64_PIECES_MIN_EDGES", 10_000)
+    big = build_plan(t(ei), t(rel), [""] * 5, 3000, 64, DEV)
+    assert (big.wlayout, big.block_nodes) == (_native.WLAYOUT_SPLIT2H, 256)
 
 
 def test_full_size_c5_shard_properties():

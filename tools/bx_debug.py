@@ -1,16 +1,17 @@
-"""Small dense cases of the d = 128 block kernels against a float64 evaluation, with WHERE the wrong rows sit (position of
+"""Small dense cases of the block kernels (D=128 default; D=64) against a float64 evaluation, with WHERE the wrong rows sit (position of
 their edges in the chunk, relation, destination).  GHF_KERNEL picks the kernel (bx / hx)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graph_hypernetwork_forge_amd import _native
 from graph_hypernetwork_forge_amd.plan import build_plan
 dev = torch.device("cuda:0")
-d = 128
+d = int(os.environ.get("D", "128"))
 rng = np.random.default_rng(3)
+B, C = (384, 76) if d == 128 else (256, 112)          # block nodes, rows per chunk
 CASES = [  # N, R, E, description
-    (384, 1, 3, "1 chunk, 3 rows"), (384, 1, 16, "1 chunk, 16 rows"), (384, 1, 20, "1 chunk, 20 rows"),
-    (384, 1, 40, "1 chunk, 40 rows"), (384, 1, 76, "1 chunk, 76 rows"), (384, 1, 77, "2 chunks 76+1"),
-    (384, 2, 60, "2 chunks ~30"), (384, 8, 400, "8 relations x ~50"), (800, 4, 700, "3 blocks"),
+    (B, 1, 3, "1 chunk, 3 rows"), (B, 1, 16, "1 chunk, 16 rows"), (B, 1, 20, "1 chunk, 20 rows"),
+    (B, 1, 40, "1 chunk, 40 rows"), (B, 1, C, "1 full chunk"), (B, 1, C + 1, "2 chunks full+1"),
+    (B, 2, 60, "2 chunks ~30"), (B, 8, 400, "8 relations x ~50"), (2 * B + 32, 4, 700, "3 blocks"), (3 * B, 3, 3000, "long blocks"),
 ]
 for N, R, E, what in CASES:
     src = rng.integers(0, N, E); dst = rng.integers(0, N, E); rel = rng.integers(0, R, E)

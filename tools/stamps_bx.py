@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from graph_hypernetwork_forge_amd import _build, _native, synth
 from graph_hypernetwork_forge_amd.plan import build_plan
-N, E, R, d = 1_000_000, 10_000_000, 64, 128
+N, E, R, d = (100_000, 1_000_000, 32, 64) if os.environ.get("D") == "64" else (1_000_000, 10_000_000, 64, 128)
 _build.build()
 lib = _native.load()
 dev = torch.device("cuda:0")
