@@ -38,7 +38,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native
-from .plan import GraphPlan, PlanCache, build_plan, build_rs, relation_ids
+from .plan import GraphPlan, PlanCache, build_plan, build_rs, plan_config, relation_ids
 
 
 @dataclass
@@ -123,8 +123,8 @@ def shard_spec(N: int, block_nodes: int, world: int, rank: int, chunks: int = 1,
 class NativeOps:
     """The product compute steps: C-ABI calls only."""
 
-    def message_config(self, d: int):
-        return _native.message_config(d)
+    def message_config(self, d: int, E: int):
+        return plan_config(d, E)
 
     def build_plan(self, edge_index, rel_ids, unique, N, d, device, **shard) -> GraphPlan:
         return build_plan(edge_index, rel_ids, unique, N, d, device,
@@ -348,9 +348,9 @@ class ShardedHyperGNN:
                             extra=(self.world, self.rank, self.chunks, self.mode, self.balance))
         if key != self._plan_key or os.environ.get("GHF_PLAN_CACHE") == "0":
             d = self.model.hidden_dim
-            bn = self.ops.message_config(d)[0]
             unique, ids = relation_ids(edge_texts)
             E = edge_index.size(1)
+            bn = self.ops.message_config(d, E)[0]
             if self.mode == "edges":
                 # contiguous ranges of the edge list; the rows are split evenly for the reduce-scatter / all-gather
                 spec = shard_spec(N, 1, self.world, self.rank, 1)

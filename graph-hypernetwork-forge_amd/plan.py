@@ -67,6 +67,15 @@ SRC_MASK = 0x0FFFFFFF
 D64_PIECES_MIN_EDGES = 4_000_000
 
 
+def plan_config(d: int, E: int) -> Tuple[int, int, int, int]:
+    """(block_nodes, weight layout, chunk_rows, split_chunks) build_plan uses for a graph of E edges (all of them: every rank
+    of a sharded run passes the whole graph's count): ghf_message_config, but small hidden-64 graphs keep the exact kernel."""
+    cfg = _native.message_config(d)
+    if d == 64 and cfg[1] == _native.WLAYOUT_SPLIT2H and not os.environ.get("GHF_KERNEL") and E < D64_PIECES_MIN_EDGES:
+        cfg = _native.exact_config(d)                    # see D64_PIECES_MIN_EDGES
+    return cfg
+
+
 def exact_plan(plan: "GraphPlan", d: int) -> "GraphPlan":
     """`plan`'s edges planned for the exact kernels (built once, kept on the plan)."""
     if plan.exact is None:
@@ -189,10 +198,7 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     if exact:                                     # the exact fp32 kernels (range guard fallback: _native.exact_config)
         bn, wl, cr, sc = _native.exact_config(d)
     else:
-        bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else _native.message_config(d)
-        if (d == 64 and wl == _native.WLAYOUT_SPLIT2H and not os.environ.get("GHF_KERNEL")
-                and edge_index.size(1) < D64_PIECES_MIN_EDGES):
-            bn, wl, cr, sc = _native.exact_config(d)         # small graph: see D64_PIECES_MIN_EDGES
+        bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else plan_config(d, edge_index.size(1))
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range

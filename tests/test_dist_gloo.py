@@ -29,7 +29,7 @@ class OracleOps:
         self.bn = block_nodes
         self.split = split           # emulate a kernel that gathers a split form: here the fp32 bits + a row "scale" of 1
 
-    def message_config(self, d):
+    def message_config(self, d, E):
         return self.bn, 0, 48, 128
 
     def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner=None, owner_bounds=None, edge_range=None):
