@@ -65,9 +65,10 @@ SIGNATURES = {
     "ghf_edge_transform_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "ghf_weights_rs_bytes": (_sz, [_i32, _i32]),
     "ghf_weights_pack_rs": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "ghf_edge_transform_h_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "ghf_edge_transform_h_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "ghf_run_rows_fwd": (_i32, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp]),
     "ghf_segment_partial_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
-    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
+    "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
     "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
@@ -401,10 +402,15 @@ def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.T
                        h_split: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Pass 1: per-edge results into Y [E, d] at the edges' destination-order positions (rs: plan.RsPlan; W_msg / W_self
     natural [R, d, d]).  Cuts the weights and — unless the caller has them (`h_split`, from the previous layer's pass 2) —
-    the rows of h into their two fp16 pieces first (or transposes the weights, rs32)."""
+    the rows of h into their two fp16 pieces first (or transposes the weights, rs32).  Plans whose rows stand for runs of
+    edges (rs.run_start: graphs with hubs) first sum every run's source rows (ghf_run_rows_fwd); the exact kernel has no
+    such rows and runs the plan's per-edge twin."""
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
+    if rs_exact() and rs.run_start is not None:
+        rs = rs.per_edge()
+        Y = rs.scratch(0, d, h.device)
     R = W_msg.size(0)
     Wm, Ws = _req(W_msg, torch.float32, "W_msg"), _req(W_self, torch.float32, "W_self")
     if rs_exact():
@@ -417,9 +423,14 @@ def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.T
         w2h = torch.empty(lib.ghf_weights_rs_bytes(R, d), dtype=torch.uint8, device=h.device)
         shift = torch.empty(R, dtype=torch.int32, device=h.device)
         _check(lib.ghf_weights_pack_rs(_ptr(Wm), _ptr(Ws), R, d, _ptr(w2h), _ptr(shift), _stream()), "ghf_weights_pack_rs")
+        xs, nx = None, 0
+        if rs.run_start is not None and rs.run_start.numel() > 1:
+            nx = rs.run_start.numel() - 1
+            xs = rs.run_scratch(nx, d)
+            _check(lib.ghf_run_rows_fwd(_ptr(h), N, d, _ptr(rs.run_src), _ptr(rs.run_start), nx, _ptr(xs), _stream()), "ghf_run_rows_fwd")
         _check(lib.ghf_edge_transform_h_fwd(_ptr(hs), N, d, _ptr(rs.src), _ptr(rs.dst), _ptr(rs.ypos), _ptr(rs.slice_tab),
-                                            rs.slice_tab.size(0), _ptr(w2h), R, _ptr(_req(bias, torch.float32, "bias")), _ptr(Y),
-                                            _stream()), "ghf_edge_transform_h_fwd")
+                                            rs.slice_tab.size(0), _ptr(w2h), R, _ptr(_req(bias, torch.float32, "bias")),
+                                            _ptr(xs), nx, _ptr(rs.cnt), _ptr(Y), _stream()), "ghf_edge_transform_h_fwd")
     if rs.hub_of is not None:                       # hubs: their rows in chunks (fixed order); pass 2 adds the chunks' sums
         _check(load().ghf_segment_partial_fwd(_ptr(Y), _ptr(rs.hub_chunks), rs.hub_chunks.size(0), d, _ptr(rs.hub_scratch(d)),
                                               _stream()), "ghf_segment_partial_fwd")
@@ -433,8 +444,11 @@ def segment_tail_fwd(Y: torch.Tensor, rs, h: Optional[torch.Tensor], ln_gamma, l
     also receives the rows in the form the next layer's pass 1 gathers."""
     N, d = h_out.shape
     rows = N - row0 if rows is None else rows
+    if rs_exact() and rs.run_start is not None:                   # (see edge_transform_fwd)
+        rs = rs.per_edge()
+        Y = rs.scratch(0, d, h_out.device)
     P = rs.hub_scratch(d) if rs.hub_of is not None else None      # filled by edge_transform_fwd
-    _check(load().ghf_segment_tail_fwd(_ptr(Y), _ptr(rs.off), _ptr(rs.hub_of), _ptr(rs.hub_tab), _ptr(P), _ptr(h), _ptr(ln_gamma),
+    _check(load().ghf_segment_tail_fwd(_ptr(Y), _ptr(rs.off), _ptr(rs.deg_of), _ptr(rs.hub_of), _ptr(rs.hub_tab), _ptr(P), _ptr(h), _ptr(ln_gamma),
                                        _ptr(ln_beta), float(ln_eps), row0, rows, d, _ptr(h_out), _ptr(h_split_out), N, flags,
                                        _stream()), "ghf_segment_tail_fwd")
     return h_out

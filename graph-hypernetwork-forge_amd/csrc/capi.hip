@@ -234,10 +234,18 @@ int ghf_weights_pack_rs(const float* W_msg, const float* W_self, int R, int d, v
 }
 
 int ghf_edge_transform_h_fwd(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
-                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
-                             void* stream) {
+                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias,
+                             const void* x_split, int64_t NX, const float* row_cnt, float* Y, void* stream) {
     GHF_REQUIRE(h_split && src && dst && ypos && slice_tab && w2h && bias && Y, "edge_transform_h_fwd: null pointer argument");
-    return launch_edge_transform_h(h_split, N, d, src, dst, ypos, slice_tab, nslices, w2h, R, bias, Y, (hipStream_t)stream);
+    GHF_REQUIRE((x_split != nullptr) == (NX > 0), "edge_transform_h_fwd: x_split and its row count go together");
+    return launch_edge_transform_h(h_split, N, d, src, dst, ypos, slice_tab, nslices, w2h, R, bias, x_split, NX, row_cnt, Y,
+                                   (hipStream_t)stream);
+}
+
+int ghf_run_rows_fwd(const float* h, int64_t N, int d, const int64_t* run_src, const int64_t* run_start, int64_t nruns,
+                     void* x_split, void* stream) {
+    GHF_REQUIRE((h && run_src && run_start && x_split) || nruns == 0, "run_rows_fwd: null pointer argument");
+    return launch_run_rows(h, N, d, run_src, run_start, nruns, x_split, (hipStream_t)stream);
 }
 
 int ghf_segment_partial_fwd(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, void* stream) {
@@ -245,14 +253,14 @@ int ghf_segment_partial_fwd(const float* Y, const int64_t* hub_chunks, int64_t n
     return launch_segment_partial(Y, hub_chunks, nchunks, d, P, (hipStream_t)stream);
 }
 
-int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
+int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* deg_of, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                          const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0,
                          int64_t rows, int d, float* h_out, void* h_split_out, int64_t n_split, int flags, void* stream) {
     GHF_REQUIRE(Y && off && h_out, "segment_tail_fwd: null pointer argument");
     GHF_REQUIRE(!hub_of || (hub_tab && P), "segment_tail_fwd: hub_of without hub_tab / P");
     GHF_REQUIRE((flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM)) || (h && ln_gamma && ln_beta), "segment_tail_fwd: tail inputs missing");
     GHF_REQUIRE(!h_split_out || n_split >= row0 + rows, "segment_tail_fwd: h_split_out has fewer rows than the range written");
-    return launch_segment_tail(Y, off, hub_of, hub_tab, P, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, h_split_out,
+    return launch_segment_tail(Y, off, deg_of, hub_of, hub_tab, P, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, h_split_out,
                                n_split, flags, (hipStream_t)stream);
 }
 

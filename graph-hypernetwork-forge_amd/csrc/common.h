@@ -190,10 +190,12 @@ int launch_edge_transform(const float* h, int64_t N, int d, const int64_t* src, 
 size_t weights_rs_bytes(int R, int d);
 int launch_weights_pack_rs(const float* Wm, const float* Ws, int R, int d, void* out, int* shift_ws, hipStream_t stream);
 int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
-                            const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
-                            hipStream_t stream);
+                            const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias,
+                            const void* x_split, int64_t NX, const float* row_cnt, float* Y, hipStream_t stream);
+int launch_run_rows(const float* h, int64_t N, int d, const int64_t* run_src, const int64_t* run_start, int64_t nruns,
+                    void* x_split, hipStream_t stream);
 int launch_segment_partial(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, hipStream_t stream);
-int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
+int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* deg_of, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                         const float* h, const float* g, const float* b, float eps, int64_t row0, int64_t rows, int d,
                         float* h_out, void* h_split_out, int64_t n_split, int flags, hipStream_t stream);
 int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream);

@@ -109,6 +109,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_YT
 #define GHF_BX_YT 0
 #endif
+#ifndef GHF_BX_PRIO
+#define GHF_BX_PRIO 0
+#endif
 #ifndef GHF_BX_CR
 #define GHF_BX_CR 76         // rows per chunk
 #endif
@@ -688,6 +691,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         BX_STAMP_FLUSH();
     } else {
         // =============================================== CONSUMERS ===============================================
+#if GHF_BX_PRIO
+        __builtin_amdgcn_s_setprio(GHF_BX_PRIO);           // (experiment) the matrix waves ahead of their SIMD's helper wave
+#endif
         // B fragments (GHF_WLAYOUT_SPLIT2H): Wh[r][o/16][kk/32][piece][lane][8] fp16, then one float 2^-s per relation
         const uint32_t wsc_off = (uint32_t)((uint64_t)R * 2 * D * D * (NPL * 2));
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wsplit, 0, (int)wsc_off, 0x00020000);

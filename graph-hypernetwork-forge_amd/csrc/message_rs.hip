@@ -134,12 +134,15 @@ template <int KH>
 __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
     const char* __restrict__ h_split, int64_t N, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
     const int64_t* __restrict__ ypos, const int64_t* __restrict__ slice_tab, const char* __restrict__ w2h, int R,
-    const float* __restrict__ bias, float* __restrict__ Y) {
+    const float* __restrict__ bias, const char* __restrict__ x_split, int64_t NX, const float* __restrict__ row_cnt,
+    float* __restrict__ Y) {
     constexpr int RS_KH = KH, GR = KH / 8, GPT = KH / 16;  // granules (8 fp16) per tile row; per thread, piece and step
     extern __shared__ __attribute__((aligned(16))) char rs_lds[];
     typedef _Float16 (*tile_t)[2][RS_TM][KH];              // [buffer][piece][row][k]
     tile_t At = (tile_t)rs_lds, Bt = (tile_t)(rs_lds + (size_t)2 * 2 * RS_TM * KH * 2);
-    float (*rsc)[RS_TM] = (float (*)[RS_TM])(rs_lds + (size_t)2 * 2 * 2 * RS_TM * KH * 2);   // 2^-s of a tile row's source / destination row
+    // per tile row: 2^-s of its source row, n 2^-s of its destination row, n — n = the number of edges the row stands for
+    // (ghf.h: rows of pre-summed runs; 1 without them, and every product below is then what it was)
+    float (*rsc)[RS_TM] = (float (*)[RS_TM])(rs_lds + (size_t)2 * 2 * 2 * RS_TM * KH * 2);
     auto swz = [](int row, int g) { return KH == 64 ? (g ^ (row & 7)) : g; };
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int c16 = lane & 15, q = lane >> 4;
@@ -152,10 +155,13 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
     const int srow = t >> 1, sg = GPT * (t & 1);
     int64_t e = e0 + srow;
     if (e >= e1) e = e1 - 1;                               // rows past the tile's end repeat its last edge (never stored)
-    const int64_t su = src[e], sv = dst[e];
+    const int64_t su = src[e], sv = dst[e];               // su < 0: row ~su of x_split (the sum of a run's source rows)
+    const char* __restrict__ urow = su >= 0 ? h_split + (size_t)su * hrow : x_split + (size_t)(~su) * hrow;
     if ((t & 1) == 0) {
-        rsc[0][srow] = hscale[su];
-        rsc[1][srow] = hscale[sv];
+        const float n = row_cnt ? row_cnt[e] : 1.0f;
+        rsc[0][srow] = su >= 0 ? hscale[su] : ((const float*)(x_split + (size_t)NX * hrow))[~su];
+        rsc[1][srow] = hscale[sv] * n;
+        rsc[2][srow] = n;
     }
     const char* __restrict__ wr = w2h + (size_t)r * 8 * d * d;          // [half][piece][n][k] fp16 = 8 d^2 bytes per relation
     const float wscale = ((const float*)(w2h + (size_t)R * 8 * d * d))[r];
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
     auto fetch = [&](int k0, Stage& S) {                   // k0: first contraction index of the step, in [0, 2d)
         const int half = k0 >= d;
         const int kk = half ? k0 - d : k0;
-        const char* arow = h_split + (size_t)(half ? sv : su) * hrow;
+        const char* arow = half ? h_split + (size_t)sv * hrow : urow;
         const char* brow = wr + ((size_t)half * 2 * d + (n0 + srow)) * (size_t)d * 2;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
@@ -275,10 +281,10 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
             const int row = 32 * w + 16 * rt + 4 * q + s;
             const int64_t ee = e0 + row;
             if (ee < e1) {
-                const float fv = rsc[1][row] * wscale;
+                const float fv = rsc[1][row] * wscale, n = rsc[2][row];
                 float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + c16;
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct) y[16 * ct] = fmaf(acc[rt][ct][s], fv, bv[ct]);
+                for (int ct = 0; ct < 8; ++ct) y[16 * ct] = fmaf(acc[rt][ct][s], fv, bv[ct] * n);
             }
         }
 }
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256) void segment_partial_kernel(const float* __res
 // latency of its few loads, so they must not queue behind each other).  Fixed summation order.
 template <int CPL>
 __global__ __launch_bounds__(256) void segment_tail_kernel(
-    const float* __restrict__ Y, const int64_t* __restrict__ off, const int32_t* __restrict__ hub_of,
+    const float* __restrict__ Y, const int64_t* __restrict__ off, const int32_t* __restrict__ deg_of, const int32_t* __restrict__ hub_of,
     const int64_t* __restrict__ hub_tab, const float* __restrict__ P, const float* __restrict__ h, const float* __restrict__ g,
     const float* __restrict__ b, float eps, int64_t row0, int64_t row_end, float* __restrict__ h_out,
     char* __restrict__ h_split_out, int64_t n_split, int no_tail, int32_t* __restrict__ range_flag) {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void segment_tail_kernel(
     const int64_t v = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= row_end) return;
     int64_t p0 = off[v], p1 = off[v + 1];
-    const int64_t indeg = p1 - p0;
+    const int64_t indeg = deg_of ? deg_of[v] : p1 - p0;      // (rows of pre-summed runs stand for several edges each)
     float hv[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) hv[c] = no_tail ? 0.f : h[(size_t)v * d + lane + 64 * c];
@@ -447,6 +453,89 @@ __global__ __launch_bounds__(256) void segment_tail_kernel(
     }
 }
 
+// Pass 0 (graphs with hubs): the layer is linear in the source rows, so the edges of one (destination, relation) run need one
+// row of pass 1 between them: x = sum of the run's source rows (here, fp32, in edge order, four rows in flight), and
+//   sum_{e in run} (h_u W_msg[r] + b[r] + h_v W_self[r]) = x W_msg[r] + n (b[r] + h_v W_self[r]).
+// One wave per run writes x cut into its two fp16 pieces (the form pass 1 gathers), row x of x_split [nruns rows, nruns scales].
+template <int CPL>
+__global__ __launch_bounds__(256) void run_rows_kernel(const float* __restrict__ h, const int64_t* __restrict__ run_src,
+                                                       const int64_t* __restrict__ run_start, int64_t nruns,
+                                                       char* __restrict__ x_split, int32_t* __restrict__ range_flag) {
+    constexpr int d = 64 * CPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t x = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (x >= nruns) return;
+    const int64_t p0 = run_start[x], p1 = run_start[x + 1];
+    float t[4][CPL];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t[a][c] = 0.f;
+    int64_t j = p0;
+    for (; j + 4 <= p1; j += 4) {
+        const float* __restrict__ r0 = h + (size_t)run_src[j] * d + lane;
+        const float* __restrict__ r1 = h + (size_t)run_src[j + 1] * d + lane;
+        const float* __restrict__ r2 = h + (size_t)run_src[j + 2] * d + lane;
+        const float* __restrict__ r3 = h + (size_t)run_src[j + 3] * d + lane;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            t[0][c] += r0[64 * c];
+            t[1][c] += r1[64 * c];
+            t[2][c] += r2[64 * c];
+            t[3][c] += r3[64 * c];
+        }
+    }
+    for (; j < p1; ++j) {
+        const float* __restrict__ r0 = h + (size_t)run_src[j] * d + lane;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) t[0][c] += r0[64 * c];
+    }
+    float v[CPL];
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        v[c] = (t[0][c] + t[1][c]) + (t[2][c] + t[3][c]);
+        mx = fmaxf(mx, fabsf(v[c]));
+    }
+    const int sh = split2h_shift(wave_absmax(mx));
+    const float up = pow2f(sh);
+    _Float16* __restrict__ sp = (_Float16*)(x_split + (size_t)x * 4 * d);
+    int tiny = 0, nz = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        _Float16 hi, lo;
+        split2h(v[c] * up, hi, lo);
+        sp[lane + 64 * c] = hi;
+        sp[d + lane + 64 * c] = lo;
+        tiny += range_tiny(v[c] * up);
+        nz += v[c] != 0.f;
+    }
+    if (lane == 0) *(float*)(x_split + (size_t)nruns * 4 * d + (size_t)x * 4) = pow2f(-sh);
+    if (__ballot(tiny != 0)) {                             // range guard (common.h)
+        tiny = (int)wave_sum((float)tiny);
+        nz = (int)wave_sum((float)nz);
+        if (lane == 0) range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
+    }
+}
+
+int launch_run_rows(const float* h, int64_t N, int d, const int64_t* run_src, const int64_t* run_start, int64_t nruns,
+                    void* x_split, hipStream_t stream) {
+    GHF_REQUIRE(message_rs_supported(d), "run_rows: d = %d is not a relation-stationary width", d);
+    if (nruns <= 0) return GHF_OK;
+    GHF_REQUIRE(cdiv(nruns, 4) < (1ll << 31), "run_rows: too many runs per launch");
+    const unsigned grid = (unsigned)cdiv(nruns, 4);
+    switch (d / 64) {
+#define GHF_RS_CASE(CPL)                                                                                                        \
+    case CPL:                                                                                                                   \
+        run_rows_kernel<CPL><<<grid, 256, 0, stream>>>(h, run_src, run_start, nruns, (char*)x_split, range_flag_ptr());          \
+        break;
+        GHF_RS_CASE(2) GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)
+#undef GHF_RS_CASE
+    }
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 // (d = 128 runs too — GHF_KERNEL=rs selects it there for A/B — but the destination-block kernel is the default at 128)
 int message_rs_supported(int d) { return d >= 128 && d <= RS_MAX_D && (d % RS_TN) == 0; }
 
@@ -474,8 +563,8 @@ int launch_weights_pack_rs(const float* Wm, const float* Ws, int R, int d, void*
 }
 
 int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
-                            const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
-                            hipStream_t stream) {
+                            const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias,
+                            const void* x_split, int64_t NX, const float* row_cnt, float* Y, hipStream_t stream) {
     GHF_REQUIRE(message_rs_supported(d), "edge_transform: d = %d has no relation-stationary kernel (d %% 128 == 0, 128 <= d <= %d)", d, RS_MAX_D);
     GHF_REQUIRE(N > 0 && nslices > 0 && nslices < (1ll << 31), "edge_transform: bad sizes");
     // (one-dimensional grid, the column tile the fast index: the workgroups that share a tile's rows run side by side
@@ -486,15 +575,15 @@ int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t
     // 32 (two workgroups per CU) on one GPU's share of C5: occupancy beats line efficiency here.  GHF_RS_K=64 for A/B.
     static const bool k64 = getenv("GHF_RS_K") && atoi(getenv("GHF_RS_K")) == 64;
     if ((d % 256) == 0 && k64) {
-        constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 64 * 2 + 2 * RS_TM * 4;
+        constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 64 * 2 + 3 * RS_TM * 4;
         GHF_SET_MAX_LDS(edge_transform_h_kernel<64>, lds);
         edge_transform_h_kernel<64><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
-                                                              (const char*)w2h, R, bias, Y);
+                                                              (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
     } else {
-        constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 32 * 2 + 2 * RS_TM * 4;
+        constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 32 * 2 + 3 * RS_TM * 4;
         GHF_SET_MAX_LDS(edge_transform_h_kernel<32>, lds);
         edge_transform_h_kernel<32><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
-                                                              (const char*)w2h, R, bias, Y);
+                                                              (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
     }
     GHF_LAUNCH_CHECK();
     return GHF_OK;
@@ -509,7 +598,7 @@ int launch_segment_partial(const float* Y, const int64_t* hub_chunks, int64_t nc
     return GHF_OK;
 }
 
-int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
+int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* deg_of, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                         const float* h, const float* g, const float* b, float eps, int64_t row0, int64_t rows, int d,
                         float* h_out, void* h_split_out, int64_t n_split, int flags, hipStream_t stream) {
     GHF_REQUIRE(message_rs_supported(d), "segment_tail: d = %d is not a relation-stationary width", d);
@@ -520,7 +609,7 @@ int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* hub_o
     switch (d / 64) {
 #define GHF_RS_CASE(CPL)                                                                                                        \
     case CPL:                                                                                                                   \
-        segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out,    \
+        segment_tail_kernel<CPL><<<grid, 256, 0, stream>>>(Y, off, deg_of, hub_of, hub_tab, P, h, g, b, eps, row0, row0 + rows, h_out,    \
                                                            (char*)h_split_out, n_split, nt, range_flag_ptr());                 \
         break;
         GHF_RS_CASE(2) GHF_RS_CASE(4) GHF_RS_CASE(6) GHF_RS_CASE(8) GHF_RS_CASE(10) GHF_RS_CASE(12) GHF_RS_CASE(14) GHF_RS_CASE(16)

@@ -33,17 +33,27 @@ def relation_ids(edge_texts: Sequence[str]) -> Tuple[List[str], np.ndarray]:
 
 @dataclass
 class RsPlan:
-    """What the relation-stationary layer (csrc/message_rs.hip, wide hidden sizes) reads besides the CSR plan."""
-    src: torch.Tensor        # [E] int64, edges in relation order (destination ascending inside a relation)
-    dst: torch.Tensor        # [E] int64
-    ypos: torch.Tensor       # [E] int64: the edge's position in destination order = its row of the per-edge results
-    slice_tab: torch.Tensor  # [S, 3] int64 (relation, first edge, end edge): tiles of at most RS_TILE edges
-    off: torch.Tensor        # [N+1] int64: a destination's rows of the per-edge results
+    """What the relation-stationary layer (csrc/message_rs.hip, wide hidden sizes) reads besides the CSR plan.  A ROW of its
+    two passes is an edge — or, in plans for graphs with hubs (run_start is not None), a run of up to RS_RUN_MAX edges of one
+    (destination, relation) pair, whose source rows are summed first (include/ghf.h: ghf_run_rows_fwd)."""
+    src: torch.Tensor        # [rows] int64, rows in relation order (destination ascending inside a relation); < 0: ~(row of the run sums)
+    dst: torch.Tensor        # [rows] int64
+    ypos: torch.Tensor       # [rows] int64: the row's position in destination order = its row of the per-row results
+    slice_tab: torch.Tensor  # [S, 3] int64 (relation, first row, end row): tiles of at most RS_TILE rows
+    off: torch.Tensor        # [N+1] int64: a destination's rows of the per-row results
+    rows: int = 0            # number of rows (= edges without runs)
     hub_of: Optional[torch.Tensor] = None      # [N] int32: hub index or -1 (None: no destination has more than RS_HUB_ROWS rows)
     hub_tab: Optional[torch.Tensor] = None     # [H, 2] int64: (first slot, slots) of a hub's chunk sums
     hub_chunks: Optional[torch.Tensor] = None  # [C, 3] int64: (first row, end row, slot)
+    cnt: Optional[torch.Tensor] = None         # [rows] float32: edges a row stands for (runs only)
+    run_src: Optional[torch.Tensor] = None     # [M] int64: the sources of the runs of two or more edges, run after run
+    run_start: Optional[torch.Tensor] = None   # [X+1] int64: run i sums run_src[run_start[i] : run_start[i+1]]
+    deg_of: Optional[torch.Tensor] = None      # [N] int32: in-degrees (the mean's divisor when rows are runs)
+    twin: Optional[object] = None              # () -> the per-edge plan of the same graph (the exact kernels have no run rows)
     _Y: Optional[torch.Tensor] = None
     _P: Optional[torch.Tensor] = None
+    _X: Optional[torch.Tensor] = None
+    _twin: Optional["RsPlan"] = None
 
     def hub_scratch(self, d: int) -> torch.Tensor:
         n = self.hub_chunks.size(0) * d
@@ -52,12 +62,27 @@ class RsPlan:
         return self._P
 
     def scratch(self, E: int, d: int, device) -> torch.Tensor:
-        if self._Y is None or self._Y.numel() < E * d:
-            self._Y = torch.empty(max(E, 1) * d, dtype=torch.float32, device=device)
+        """The per-row results [rows, d] (E: the caller's edge count — what `rows` is without runs)."""
+        n = self.rows or E
+        if self._Y is None or self._Y.numel() < n * d:
+            self._Y = torch.empty(max(n, 1) * d, dtype=torch.float32, device=device)
         return self._Y
+
+    def run_scratch(self, nruns: int, d: int) -> torch.Tensor:
+        n = _native.load().ghf_split_rows_bytes(nruns, d, _native.WLAYOUT_SPLIT2H)
+        if self._X is None or self._X.numel() < n:
+            self._X = torch.empty(n, dtype=torch.uint8, device=self.off.device)
+        return self._X
+
+    def per_edge(self) -> "RsPlan":
+        if self._twin is None:
+            self._twin = self.twin()
+        return self._twin
 
 
 RS_TILE = 128
+RS_RUN_MAX = 256            # edges per row of a run plan: longer (destination, relation) runs are cut (a wave sums a row's sources)
+RS_RUNS_MAX_SHARE = 0.75    # runs pay when they leave at most this share of the rows (they cost one more pass over the sources)
 RS_HUB_ROWS = 4096           # a destination with more rows than this is summed in chunks of this many by whole workgroups
 SRC_MASK = 0x0FFFFFFF
 # d = 64: the two-fp16-piece kernel (message_bx<64>) is 1.4x the exact fp32-MFMA kernel per edge, but its forward ends with the
@@ -85,41 +110,96 @@ def exact_plan(plan: "GraphPlan", d: int) -> "GraphPlan":
     return plan.exact
 
 
-def build_rs(plan: "GraphPlan") -> RsPlan:
-    """From a CSR plan (block_nodes == 1: edges sorted by key = dst * R + relation): the same edges grouped by relation.
-    One device sort and one host sync per plan."""
-    if plan.block_nodes != 1:
-        raise ValueError("the relation-stationary layer runs on CSR plans (block_nodes == 1)")
-    dev, R, N, E = plan.sorted_key.device, plan.R, plan.N, plan.E
-    off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-    off[1:] = torch.cumsum(plan.indeg.to(torch.int64), 0)
-    if E == 0:
-        z = torch.zeros(1, dtype=torch.int64, device=dev)
-        return RsPlan(src=z, dst=z, ypos=z, slice_tab=torch.zeros(0, 3, dtype=torch.int64, device=dev), off=off)
-    key = plan.sorted_key[:E].to(torch.int64) & 0xFFFFFFFF
-    dst, rel = torch.div(key, R, rounding_mode="floor"), key % R
-    src = plan.sorted_src[:E].to(torch.int64) & SRC_MASK
-    perm = torch.sort(rel, stable=True).indices
-    counts = torch.bincount(rel, minlength=R).cpu().tolist()
+def _hub_tables(rs: RsPlan, rows_of: torch.Tensor, N: int, dev) -> None:
+    """Destinations with more than RS_HUB_ROWS rows: their rows are summed in chunks first (segment_partial)."""
+    hubs = torch.nonzero(rows_of > RS_HUB_ROWS).flatten()
+    if not hubs.numel():
+        return
+    hub_nodes = hubs.cpu().tolist()
+    starts = rs.off.index_select(0, hubs).cpu().tolist()
+    ends = rs.off.index_select(0, hubs + 1).cpu().tolist()
+    chunks, htab = [], []
+    for a, b_ in zip(starts, ends):
+        htab.append((len(chunks), -(-(b_ - a) // RS_HUB_ROWS)))
+        chunks += [(p, min(p + RS_HUB_ROWS, b_), len(chunks) + i) for i, p in enumerate(range(a, b_, RS_HUB_ROWS))]
+    hub_of = torch.full((N,), -1, dtype=torch.int32)
+    hub_of[torch.tensor(hub_nodes)] = torch.arange(len(hub_nodes), dtype=torch.int32)
+    rs.hub_of, rs.hub_tab = hub_of.to(dev), torch.tensor(htab, dtype=torch.int64).to(dev)
+    rs.hub_chunks = torch.tensor(chunks, dtype=torch.int64).to(dev)
+
+
+def _slices(counts: List[int]) -> List[Tuple[int, int, int]]:
     tab, e = [], 0
     for r, c in enumerate(counts):
         tab += [(r, a, min(a + RS_TILE, e + c)) for a in range(e, e + c, RS_TILE)]
         e += c
+    return tab
+
+
+def build_rs(plan: "GraphPlan", runs: Optional[bool] = None) -> RsPlan:
+    """From a CSR plan (block_nodes == 1: edges sorted by key = dst * R + relation): the same edges grouped by relation.
+    One device sort and a few host syncs per plan.  runs: rows = runs of equal (destination, relation) (None: when that
+    leaves at most RS_RUNS_MAX_SHARE of the rows — power-law graphs: a hub's edges repeat its relations; GHF_RS_RUNS=0/1
+    forces)."""
+    if plan.block_nodes != 1:
+        raise ValueError("the relation-stationary layer runs on CSR plans (block_nodes == 1)")
+    dev, R, N, E = plan.sorted_key.device, plan.R, plan.N, plan.E
+    if E == 0:
+        z = torch.zeros(1, dtype=torch.int64, device=dev)
+        return RsPlan(src=z, dst=z, ypos=z, slice_tab=torch.zeros(0, 3, dtype=torch.int64, device=dev),
+                      off=torch.zeros(N + 1, dtype=torch.int64, device=dev))
+    key = plan.sorted_key[:E].to(torch.int64) & 0xFFFFFFFF
+    src = plan.sorted_src[:E].to(torch.int64) & SRC_MASK
+    if os.environ.get("GHF_RS_RUNS") in ("0", "1"):
+        runs = os.environ["GHF_RS_RUNS"] == "1"
+    if runs is None or runs:
+        head = torch.ones(E, dtype=torch.bool, device=dev)
+        head[1:] = key[1:] != key[:-1]
+        lo = torch.nonzero(head).flatten()                            # first edge of every (dst, rel) run
+        n = torch.diff(lo, append=torch.tensor([E], device=dev))
+        per = torch.div(n + (RS_RUN_MAX - 1), RS_RUN_MAX, rounding_mode="floor")      # rows of a run (long runs are cut)
+        rows = int(per.sum().item())
+        if runs or rows <= RS_RUNS_MAX_SHARE * E:
+            return _build_rs_runs(plan, key, src, lo, n, per, rows)
+    off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(plan.indeg.to(torch.int64), 0)
+    dst, rel = torch.div(key, R, rounding_mode="floor"), key % R
+    perm = torch.sort(rel, stable=True).indices
+    counts = torch.bincount(rel, minlength=R).cpu().tolist()
     rs = RsPlan(src=src.index_select(0, perm).contiguous(), dst=dst.index_select(0, perm).contiguous(), ypos=perm.contiguous(),
-                slice_tab=torch.tensor(tab, dtype=torch.int64).to(dev), off=off)
-    hubs = torch.nonzero(plan.indeg > RS_HUB_ROWS).flatten()
-    if hubs.numel():
-        hub_nodes = hubs.cpu().tolist()
-        starts = off.index_select(0, hubs).cpu().tolist()
-        ends = off.index_select(0, hubs + 1).cpu().tolist()
-        chunks, htab = [], []
-        for a, b_ in zip(starts, ends):
-            htab.append((len(chunks), -(-(b_ - a) // RS_HUB_ROWS)))
-            chunks += [(p, min(p + RS_HUB_ROWS, b_), len(chunks) + i) for i, p in enumerate(range(a, b_, RS_HUB_ROWS))]
-        hub_of = torch.full((N,), -1, dtype=torch.int32)
-        hub_of[torch.tensor(hub_nodes)] = torch.arange(len(hub_nodes), dtype=torch.int32)
-        rs.hub_of, rs.hub_tab = hub_of.to(dev), torch.tensor(htab, dtype=torch.int64).to(dev)
-        rs.hub_chunks = torch.tensor(chunks, dtype=torch.int64).to(dev)
+                slice_tab=torch.tensor(_slices(counts), dtype=torch.int64).to(dev), off=off, rows=E)
+    _hub_tables(rs, plan.indeg, N, dev)
+    return rs
+
+
+def _build_rs_runs(plan: "GraphPlan", key, src, lo, n, per, rows: int) -> RsPlan:
+    dev, R, N, E = key.device, plan.R, plan.N, plan.E
+    first = torch.cumsum(per, 0) - per                                 # first row of every run
+    run_of = torch.repeat_interleave(torch.arange(lo.numel(), device=dev), per, output_size=rows)
+    j = torch.arange(rows, device=dev) - first.index_select(0, run_of)
+    r_lo = lo.index_select(0, run_of) + RS_RUN_MAX * j                  # a row's edges: [r_lo, r_lo + r_n) in CSR order
+    r_n = torch.minimum(n.index_select(0, run_of) - RS_RUN_MAX * j, torch.tensor(RS_RUN_MAX, device=dev))
+    k0 = key.index_select(0, r_lo)
+    r_dst, r_rel = torch.div(k0, R, rounding_mode="floor"), k0 % R
+    multi = r_n > 1
+    x_of = torch.cumsum(multi.to(torch.int64), 0) - 1                   # row of the run sums, for rows of two or more edges
+    code = torch.where(multi, -x_of - 1, src.index_select(0, r_lo))
+    m_lo, m_n = r_lo[multi], r_n[multi]
+    run_start = torch.zeros(m_n.numel() + 1, dtype=torch.int64, device=dev)
+    run_start[1:] = torch.cumsum(m_n, 0)
+    M = int(run_start[-1].item())
+    which = torch.repeat_interleave(torch.arange(m_n.numel(), device=dev), m_n, output_size=M)
+    run_src = src.index_select(0, torch.arange(M, device=dev) - run_start.index_select(0, which) + m_lo.index_select(0, which))
+    perm = torch.sort(r_rel, stable=True).indices                       # rows are in destination order: ascending inside a relation
+    counts = torch.bincount(r_rel, minlength=R).cpu().tolist()
+    rows_of = torch.bincount(r_dst, minlength=N)
+    off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(rows_of, 0)
+    rs = RsPlan(src=code.index_select(0, perm).contiguous(), dst=r_dst.index_select(0, perm).contiguous(), ypos=perm.contiguous(),
+                slice_tab=torch.tensor(_slices(counts), dtype=torch.int64).to(dev), off=off, rows=rows,
+                cnt=r_n.index_select(0, perm).to(torch.float32).contiguous(), run_src=run_src.contiguous(), run_start=run_start,
+                deg_of=plan.indeg, twin=lambda: build_rs(plan, runs=False))
+    _hub_tables(rs, rows_of, N, dev)
     return rs
 
 

@@ -201,25 +201,34 @@ int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
  *   ghf_edge_transform_h_fwd: the same per-edge results with the two-fp16-piece contraction of the d = 128 kernel (three
  *       16x16x32 products, 22 significand bits, 5x less matrix time): h_split = ghf_split_rows(h, GHF_WLAYOUT_SPLIT2H), w2h =
  *       ghf_weights_pack_rs(W_msg, W_self natural [R][d][d]) (ghf_weights_rs_bytes(R, d) bytes; shift_ws: R ints of scratch).
+ *       Rows that stand for several edges (graphs with hubs): the layer is linear in the source rows, so the n edges of one
+ *       (destination, relation) run need one row of this pass:  sum_e (h_u W_msg[r] + b[r] + h_v W_self[r]) =
+ *       x W_msg[r] + n (b[r] + h_v W_self[r]),  x = the sum of the run's source rows.  ghf_run_rows_fwd writes those sums:
+ *       x_split row i = sum of h[run_src[run_start[i] .. run_start[i+1])] (fp32, in that order) in ghf_split_rows form
+ *       (ghf_split_rows_bytes(nruns, d, SPLIT2H) bytes).  A row k of this pass then has src[k] < 0 = row ~src[k] of x_split
+ *       (NX rows; NULL / 0: none) and row_cnt[k] = n (float; NULL: every row is one edge).
  *   ghf_segment_partial_fwd (hubs only): P[slot] = sum(Y[first .. end)) for every (first, end, slot) of hub_chunks
  *       [nchunks][3] int64 — a destination with more rows than one wave should walk is summed in chunks first.
  *   ghf_segment_tail_fwd: rows [row0, row0+rows): out_v = sum(Y[off[v] .. off[v+1])) / max(indeg, 1), then the tail of
  *       ghf_tail_fwd (flags: GHF_FLAG_NO_TAIL / GHF_FLAG_RAW_SUM as for the message layer); off [N+1] int64.  Hubs:
  *       hub_of [N] int32 (hub index or -1; NULL = no hubs), hub_tab [H][2] int64 (first slot, slots) select rows of P
- *       to add instead of rows of Y; the mean still divides by off[v+1] - off[v].  h_split_out (optional): the rows
+ *       to add instead of rows of Y; the mean divides by deg_of[v] (int32 [N]: the in-degree, when rows stand for several
+ *       edges) or, deg_of == NULL, by off[v+1] - off[v].  h_split_out (optional): the rows
  *       written, also in ghf_split_rows(.., GHF_WLAYOUT_SPLIT2H) form for the next layer's ghf_edge_transform_h_fwd — a buffer
  *       of n_split rows (ghf_split_rows_bytes(n_split, d, GHF_WLAYOUT_SPLIT2H)). */
 size_t ghf_weights_rs_bytes(int R, int d);
 int ghf_weights_pack_rs(const float* W_msg, const float* W_self, int R, int d, void* w2h, int* shift_ws, void* stream);
 int ghf_edge_transform_h_fwd(const void* h_split, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
-                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias, float* Y,
-                             void* stream);
+                             const int64_t* slice_tab, int64_t nslices, const void* w2h, int R, const float* bias,
+                             const void* x_split, int64_t NX, const float* row_cnt, float* Y, void* stream);
+int ghf_run_rows_fwd(const float* h, int64_t N, int d, const int64_t* run_src, const int64_t* run_start, int64_t nruns,
+                     void* x_split, void* stream);
 int ghf_segment_partial_fwd(const float* Y, const int64_t* hub_chunks, int64_t nchunks, int d, float* P, void* stream);
 int ghf_message_rs_supported(int d);
 int ghf_edge_transform_fwd(const float* h, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
                            const int64_t* slice_tab, int64_t nslices, const float* WmT, const float* WsT, const float* bias,
                            float* Y, void* stream);
-int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
+int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* deg_of, const int32_t* hub_of, const int64_t* hub_tab, const float* P,
                          const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps, int64_t row0,
                          int64_t rows, int d, float* h_out, void* h_split_out, int64_t n_split, int flags, void* stream);
 

@@ -777,11 +777,13 @@ def test_captured_hip_graph_replays_the_forward(name):
 
 @pytest.mark.parametrize("d,N,E,R,kind", [(256, 700, 9000, 9, "uniform"), (256, 300, 20000, 5, "powerlaw"), (384, 90, 60, 7, "uniform"),
                                           (256, 1500, 1200, 40, "powerlaw")])
-@pytest.mark.parametrize("exact", [False, True])
-def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, exact, monkeypatch):
+@pytest.mark.parametrize("exact,runs", [(False, False), (True, False), (False, True), (True, True)])
+def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, exact, runs, monkeypatch):
     """csrc/message_rs.hip (d % 128 == 0, d >= 256): per-edge results in relation order + destination sums + tail against
     the oracle and against the generic kernel; tiles shorter than 128 edges, relations without edges, hubs, isolated rows,
-    row ranges, NO_TAIL and RAW_SUM."""
+    row ranges, NO_TAIL and RAW_SUM.  runs: the rows of the two passes are runs of equal (destination, relation) whose
+    source rows are summed first (long runs cut at RS_RUN_MAX — 16 here, so that the power-law hubs have cut runs); the
+    exact kernel then runs the plan's per-edge twin."""
     from graph_hypernetwork_forge_amd import plan as plan_mod
     from graph_hypernetwork_forge_amd.plan import build_rs
     if exact:
@@ -792,13 +794,22 @@ def test_wide_rows_layer_matches_oracle(d, N, E, R, kind, exact, monkeypatch):
     th = torch.from_numpy
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
     assert plan.block_nodes == 1 and _native.rs_supported(d)
-    monkeypatch.setattr(plan_mod, "RS_HUB_ROWS", 700)                   # a hub's rows in chunks at this size
-    rs = build_rs(plan)
-    assert rs.slice_tab.size(0) >= E // 128 and int(rs.off[-1]) == E
+    monkeypatch.setattr(plan_mod, "RS_HUB_ROWS", 700 if not runs else 150)   # a hub's rows in chunks at this size
+    monkeypatch.setattr(plan_mod, "RS_RUN_MAX", 16)
+    rs = build_rs(plan, runs=runs)
+    if runs:
+        key = ei[1].astype(np.int64) * R + rel
+        _, n = np.unique(key, return_counts=True)
+        assert rs.rows == int((-(-n // 16)).sum()) == int(rs.off[-1]) and rs.rows < E
+        assert rs.run_start.numel() - 1 == int((n // 16 + (n % 16 >= 2)).sum()), "rows of two or more edges have a summed source row"
+        assert abs(float(rs.cnt.sum()) - E) < 0.5
+    else:
+        assert rs.slice_tab.size(0) >= E // 128 and int(rs.off[-1]) == E and rs.run_start is None
     assert (rs.hub_of is not None) == (kind == "powerlaw" and E > 5000), "the power-law cases must exercise the hub path"
-    Y = torch.full((E, d), float("nan"), device=DEV)
+    Y = torch.full((rs.rows, d), float("nan"), device=DEV)
     _native.edge_transform_fwd(t(h), rs, t(Wm), t(Ws), t(b), Y)
-    assert bool(torch.isfinite(Y).all()), "every edge's row of the per-edge results is written"
+    if not (exact and runs):                                            # (the exact kernel wrote its own per-edge results)
+        assert bool(torch.isfinite(Y).all()), "every row of the per-row results is written"
     agg = O.message_passing_factorised(th(h), th(ei), th(rel), th(Wm), th(Ws), th(b))
     ref = O.layer_tail(agg, th(h), th(gamma), th(beta))
     out = torch.empty(N, d, device=DEV)
@@ -1173,21 +1184,28 @@ def test_hidden_64_default_kernel_follows_the_graph_size(monkeypatch):
     assert (big.wlayout, big.block_nodes) == (_native.WLAYOUT_SPLIT2H, 256)
 
 
-def test_full_size_c5_shard_properties():
+@pytest.mark.parametrize("runs", [False, None])
+def test_full_size_c5_shard_properties(runs):
     """One GPU's share of BASELINE config 5 (power-law KG, 4 M rows resident, 8 M in-edges owned, 256 relations, hidden 256)
     through the relation-stationary layer — with the graph's real hubs (in-degrees far above plan.RS_HUB_ROWS, no patched
     threshold): bitwise reproducible, LayerNorm moments, isolated rows, and sampled rows INCLUDING the hubs against a
-    float64 evaluation of their in-edge subgraph (reference statement: models/hypergnn.py:201-230, 288-296)."""
+    float64 evaluation of their in-edge subgraph (reference statement: models/hypergnn.py:201-230, 288-296).  runs=False: one
+    row per edge, the hubs' rows summed in chunks; runs=None: what the plan picks for this graph — one row per run of equal
+    (destination, relation), the hubs' source rows summed first."""
     from graph_hypernetwork_forge_amd import plan as plan_mod
     N, E, R, d = 4_000_000, 8_000_000, 256, 256
     ei, rel = synth.make_graph_arrays(N, E, R, seed=1005, kind="powerlaw")
     t = lambda a: torch.from_numpy(a).to(DEV)                                             # noqa: E731
     plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
     assert plan.block_nodes == 1 and plan.E == E and _native.rs_supported(d)
-    rs = plan_mod.build_rs(plan)
+    rs = plan_mod.build_rs(plan, runs=runs)
     deg = np.bincount(ei[1], minlength=N)
     hubs = np.argsort(deg)[-3:]
-    assert rs.hub_of is not None and deg[hubs].min() > 4 * plan_mod.RS_HUB_ROWS, "this shard must hold real hubs"
+    assert deg[hubs].min() > 4 * plan_mod.RS_HUB_ROWS, "this shard must hold real hubs"
+    if runs is False:
+        assert rs.hub_of is not None and rs.run_start is None and rs.rows == E
+    else:
+        assert rs.run_start is not None and rs.rows <= plan_mod.RS_RUNS_MAX_SHARE * E, "a power-law shard's plan sums its runs first"
     g = torch.Generator(device="cpu").manual_seed(2)
     h = torch.randn(N, d, generator=g)
     Wm, Ws = synth.normal(12, "Wm", (R, d, d), std=0.05), synth.normal(12, "Ws", (R, d, d), std=0.05)
