@@ -320,14 +320,16 @@ def main():
             if not all(any(w_ in n for n in names) for w_ in want):
                 pmc = {}                                    # counters of another kernel: not this run's traffic
         if pmc:
-            parts = [pmc] if "kernels" not in pmc else [v for k, v in pmc["kernels"].items() if "edge_transform" in k or "segment_tail" in k]
+            layer_kernels = ("edge_transform", "segment_tail", "segment_partial", "run_rows", "split2h_rows", "rs_w")   # one launch each per layer
+            parts = [pmc] if "kernels" not in pmc else [v for k, v in pmc["kernels"].items() if any(n in k for n in layer_kernels)]
             traffic = sum((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for v in parts)
             traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, KiB; FETCH x2; per-launch means" + \
                           (", summed over the layer's kernels)" if len(parts) > 1 else ")")
         kern = {_native.WLAYOUT_SPLIT2H: kern_name(plan, d) + "<%d>" % d}.get(
             plan.wlayout, "message_pp_kernel<%d>" % d if plan.block_nodes > 1 else "message_generic_kernel")
         if wide:
-            kern = "edge_transform_kernel + segment_tail_kernel<%d> (one layer)" % (d // 64)
+            kern = ("run_rows_kernel + " if plan.rs is not None and plan.rs.run_start is not None else "") + \
+                   "edge_transform%s_kernel + segment_tail_kernel<%d> (one layer, cutting rows and weights included)" % ("" if _native.rs_exact() else "_h", d // 64)
         # matrix work the kernel issues per algorithmic flop: 3 fp16 products (bx, hx), 1 fp32 (pp)
         prod, mpeak = {_native.WLAYOUT_SPLIT2H: (3, F16_MATRIX_PEAK_TF)}.get(
             plan.wlayout, (1, FP32_MATRIX_PEAK_TF))
