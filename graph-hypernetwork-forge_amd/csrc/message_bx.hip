@@ -1,33 +1,36 @@
-// message_bx.hip — K2+K3 for hidden 128 with the block sums in REGISTERS (reference: models/hypergnn.py:201-230, 288-296).
+// message_bx.hip — K2+K3 for hidden 128 and 64 with the block sums in REGISTERS (reference: models/hypergnn.py:201-230, 288-296).
 //
 // message_hx.hip keeps a destination block's fp32 sums in LDS, which caps the block at 216 nodes; a (block, relation)
 // chunk then has ~34 rows at C3 and the relation's 128 KB of weights is pulled through the CU's 64 B/clk vector-memory
-// path once per 34 rows (38 GB per launch: profiles/r01_message_kernel_pmc.json).  The register file of a CU is 512 KB
-// against 160 KB of LDS, and most of it was idle.  Here:
+// path once per 34 rows (54 GB through L2 per launch: profiles/r01_message_kernel_pmc.json).  The register file of a CU is
+// 512 KB against 160 KB of LDS, and most of it was idle.  Here (d = 128; BxCfg<64> below for hidden 64):
 //
-//   * the block is BN = 384 nodes (chunks of ~60 rows: 1.8x the rows per weight fetch, 0.56x the chunks);
+//   * the block is BN = 384 nodes (chunks of ~60 rows: 1.8x the rows per weight fetch, 0.57x the chunks);
 //   * waves 4-7 (HELPERS) own the block sums: lane l of helper wave hw holds U "units" of UW consecutive sum positions of
-//     a node — unit u = U*l + k is part (u % NU) of node 96*hw + u / NU, NU = 128 / UW — as plain VGPRs with compile-time
+//     a node — unit u = U*l + k is part (u % NU) of node NPW*hw + u / NU, NU = d / UW — as plain VGPRs with compile-time
 //     indices (192 registers per lane at BN = 384);
 //   * waves 0-3 (CONSUMERS) run the contraction exactly as message_hx.hip does (same SPLIT2H weights, same row pieces,
 //     three v_mfma_f32_16x16x32_f16 per product, B fragments in a register ring refilled straight from L2) and write a
-//     chunk's finished rows Y [rows][128] fp32 to an LDS staging tile instead of scattering them;
+//     chunk's finished rows Y [rows][d] fp32 to an LDS staging tile instead of scattering them;
 //   * the helpers FOLD the staged rows into their registers: a table node -> row (written per chunk) tells every owner
 //     lane which staged row, if any, belongs to its node; it reads that row's part with ds_read_b128 and adds it.  Rows
 //     of one chunk with equal destinations (a run; rows are sorted by destination) are first added into the run's last
 //     row by the wave that owns the destination, in ascending order.  No atomics, no dynamic register index, fixed
 //     order: bitwise reproducible;
 //   * the helpers gather the A tiles with LDS-DMA (buffer_load_dwordx4 ... lds, per-lane source address, 1 KiB per wave
-//     instruction, the XOR swizzle applied on the source side): no staging registers, no ds_write.  Source rows (HBM) are
-//     requested two stages ahead into one of two tiles, destination rows (L2) one stage ahead;
-//   * the fused tail runs from LDS after the helpers have dumped their registers there (two halves of 192 nodes).
+//     instruction, the XOR swizzle applied on the source side): no staging registers, no ds_write;
+//   * the fused tail runs from LDS after the helpers have dumped their registers there (two halves of the block).
 //
-// LDS (CR = 76 rows per chunk): P0a, P0b (source-row tiles), P1 (destination-row tile), Y (staging), 38,912 bytes each;
-// table [BN]; four chunk descriptors ("meta": the rows' scales and node ids).  A stage = one K-phase of one chunk; one
-// workgroup barrier per stage:
-//   stage (k,0)  consumers: phase 0 (h_src x W_msg) from P0[k&1]          helpers: DMA P1 <- dst rows of chunk k; fold Y(k-1)
-//   stage (k,1)  consumers: phase 1 (h_dst x W_self) from P1, write Y(k)   helpers: DMA P0[k&1] <- src rows of chunk k+2;
-//                                                                                   table of chunk k; descriptor of chunk k+3
+// LDS: P0[2] (source-row tiles), P1[2] (destination-row tiles), CR * 4d bytes each; table [BN]; four chunk descriptors
+// ("meta": the rows' scales and node ids); a KiB for DMA pieces past a tile, 128 bytes of zeros, eight flag words.
+// ONE workgroup barrier per chunk.  During chunk k (between barriers k and k + 1):
+//   consumers: phase 0 (h_src x W_msg) from P0[k&1], phase 1 (h_dst x W_self) from P1[k&1]; once all four have read that
+//              tile (flag words), the chunk's rows Y(k) overwrite it
+//   helpers:   DMA P0[(k+1)&1] <- source rows of chunk k+1 (HBM: a whole chunk to land); fold Y(k-1) out of P1[(k-1)&1];
+//              once all four have folded (flag words), DMA that tile <- destination rows of chunk k+1 (L2); table of
+//              chunk k; the descriptor pipeline (chunk_tab entry k+5, edge words k+4, row scales k+3, publish k+2)
+// Template parameter SKIP: the instances for the backward's two gradient passes, whose weights have one zero half
+// (GHF_FLAG_ZERO_SRC / GHF_FLAG_ZERO_DST): that half's gathers and products are compiled out.
 #include "common.h"
 
 #include <stdlib.h>
