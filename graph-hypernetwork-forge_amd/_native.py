@@ -44,7 +44,7 @@ SIGNATURES = {
     "ghf_plan_build": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp]),
     "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
-                                 _vp, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp]),
     "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ghf_text_encode_fwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ghf_message_layer_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
@@ -56,7 +56,7 @@ SIGNATURES = {
     "ghf_weights_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "ghf_group_workspace_bytes": (_sz, [_i64]),
     "ghf_group_edges": (_i32, [_vp, _i64, _i32, _vp, _sz, _vp, _vp, _vp]),
-    "ghf_tail_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ghf_tail_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ghf_colsum_workspace_floats": (_sz, [_i64, _i32]),
     "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ghf_relu_mask": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -75,12 +75,12 @@ SIGNATURES = {
     "ghf_add3": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ghf_dot": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
-    "ghf_weightgen_acts": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ghf_weightgen_acts": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ghf_text_encode_bwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_transpose_batched": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ghf_weights_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ghf_score_pairs_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
-    "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp]),
+    "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "ghf_set_range_flag": (_i32, [_vp]),
 }
 
@@ -237,9 +237,11 @@ def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, b
 
 def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], log_scales: Sequence[torch.Tensor],
                   T: int, Hh: int, num_hidden: int, d_in: int, d_out: int, layout: int,
-                  out: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]] = None):
+                  out: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]] = None,
+                  hidden_drop: Optional[torch.Tensor] = None):
     """head_params: flat list [head][layer][weight,bias]; log_scales: the three 1-element tensors (W_msg, W_self, bias),
-    read in place; returns (W_msg or Wfrag, W_self or None, bias)."""
+    read in place; hidden_drop: scaled dropout masks [3, num_hidden, R, Hh] of the hidden activations (training);
+    returns (W_msg or Wfrag, W_self or None, bias)."""
     lib = load()
     x = _req(text_emb, torch.float32, "text_emb")
     R = x.size(0)
@@ -264,7 +266,8 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
     else:
         W_msg, W_self, bias = out
     _check(lib.ghf_weightgen_fwd(_ptr(x), arr, ls, R, T, Hh, num_hidden, d_in, d_out, layout,
-                                 _ptr(hidden_ws), _ptr(W_msg), _ptr(W_self), _ptr(bias), _stream()),
+                                 _ptr(hidden_ws), _ptr(W_msg), _ptr(W_self), _ptr(bias),
+                                 _ptr(None if hidden_drop is None else _req(hidden_drop, torch.float32, "hidden_drop")), _stream()),
            "ghf_weightgen_fwd")
     return W_msg, W_self, bias
 
@@ -468,14 +471,15 @@ def group_edges(rel_id: torch.Tensor, R: int):
     return perm, goff
 
 
-def tail_bwd(grad_out: torch.Tensor, agg: torch.Tensor, h: torch.Tensor, gamma: torch.Tensor, eps: float, indeg: torch.Tensor):
-    """(dpre, G, T) of include/ghf.h: ghf_tail_bwd."""
+def tail_bwd(grad_out: torch.Tensor, agg: torch.Tensor, h: torch.Tensor, gamma: torch.Tensor, eps: float, indeg: torch.Tensor,
+             drop: Optional[torch.Tensor] = None):
+    """(dpre, G, T) of include/ghf.h: ghf_tail_bwd (drop: the forward's scaled dropout mask, if any)."""
     g = _req(grad_out, torch.float32, "grad_out")
     N, d = h.shape
     dpre, G, T = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
     _check(load().ghf_tail_bwd(_ptr(g), _ptr(_req(agg, torch.float32, "agg")), _ptr(_req(h, torch.float32, "h")),
                                _ptr(_req(gamma, torch.float32, "gamma")), float(eps), _ptr(indeg), N, d, _ptr(dpre), _ptr(G),
-                               _ptr(T), _stream()), "ghf_tail_bwd")
+                               _ptr(T), _ptr(None if drop is None else _req(drop, torch.float32, "drop")), _stream()), "ghf_tail_bwd")
     return dpre, G, T
 
 
@@ -608,13 +612,17 @@ def dot(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def weightgen_acts(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], T: int, Hh: int, num_hidden: int) -> torch.Tensor:
-    """[3, num_hidden, R, Hh]: the post-ReLU hidden activations of the three generator heads."""
+def weightgen_acts(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], T: int, Hh: int, num_hidden: int,
+                   hidden_drop: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[3, num_hidden, R, Hh]: the hidden activations of the three generator heads (post-ReLU, and post-dropout when the
+    forward's masks are given)."""
     x = _req(text_emb, torch.float32, "text_emb")
     keep = [_req(p, torch.float32, "weight-generator parameter") for p in head_params]
     arr = (_vp * len(keep))(*[p.data_ptr() for p in keep])
     acts = torch.empty(3, num_hidden, x.size(0), Hh, dtype=torch.float32, device=x.device)
-    _check(load().ghf_weightgen_acts(_ptr(x), arr, x.size(0), T, Hh, num_hidden, _ptr(acts), _stream()), "ghf_weightgen_acts")
+    _check(load().ghf_weightgen_acts(_ptr(x), arr, x.size(0), T, Hh, num_hidden, _ptr(acts),
+                                     _ptr(None if hidden_drop is None else _req(hidden_drop, torch.float32, "hidden_drop")), _stream()),
+           "ghf_weightgen_acts")
     return acts
 
 
@@ -655,11 +663,11 @@ def weights_pack(top: Optional[torch.Tensor], bottom: Optional[torch.Tensor], tr
 
 
 def tail_fwd(agg: torch.Tensor, h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta: torch.Tensor, ln_eps: float,
-             h_out: torch.Tensor, row0: int = 0, rows: Optional[int] = None) -> torch.Tensor:
+             h_out: torch.Tensor, row0: int = 0, rows: Optional[int] = None, drop: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = load()
     N, d = h.shape
     if rows is None:
         rows = N - row0
     _check(lib.ghf_tail_fwd(_ptr(agg), _ptr(h), _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows, d,
-                            _ptr(h_out), _stream()), "ghf_tail_fwd")
+                            _ptr(h_out), _ptr(None if drop is None else _req(drop, torch.float32, "drop")), _stream()), "ghf_tail_fwd")
     return h_out

@@ -137,12 +137,14 @@ class MessageLayerFn(torch.autograd.Function):
     """One HyperGNN layer (reference hypergnn.py:281-296) with per-relation weights in natural layout."""
 
     @staticmethod
-    def forward(ctx, h, W_msg, W_self, bias, gamma, beta, eps: float, tp: TrainPlan):
+    def forward(ctx, h, W_msg, W_self, bias, gamma, beta, eps: float, tp: TrainPlan, drop: Optional[torch.Tensor] = None):
+        """drop: the layer's dropout mask scaled by 1/(1-p) ([N, d]; reference hypergnn.py:293-294: between ReLU and LayerNorm),
+        None without dropout."""
         plan = tp.fwd
         h = h.contiguous()
         W, W2 = _layer_weights(plan, W_msg.detach(), W_self.detach(), transpose=False)
         out = torch.empty_like(h)
-        if _native.side_output_supported(plan, h.size(1)):             # one launch: h', the aggregate, the next layer's split rows
+        if drop is None and _native.side_output_supported(plan, h.size(1)):   # one launch: h', the aggregate, the next layer's split rows
             agg = torch.empty_like(h)
             hs = tp.carry.take(h)
             if hs is None:
@@ -153,9 +155,9 @@ class MessageLayerFn(torch.autograd.Function):
             tp.carry.put(out, hs_out)
         else:
             agg = _message(h, plan, W, W2, bias.detach().contiguous(), _native.GHF_FLAG_NO_TAIL)
-            _native.tail_fwd(agg, h, gamma.detach(), beta.detach(), eps, out)
+            _native.tail_fwd(agg, h, gamma.detach(), beta.detach(), eps, out, drop=drop)
         ctx.save_for_backward(h, agg, W_msg, W_self, gamma)
-        ctx.tp, ctx.eps = tp, eps
+        ctx.tp, ctx.eps, ctx.drop = tp, eps, drop
         return out
 
     @staticmethod
@@ -164,7 +166,7 @@ class MessageLayerFn(torch.autograd.Function):
         tp: TrainPlan = ctx.tp
         plan = tp.fwd
         g = grad_out.contiguous().float()
-        dpre, G, T = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg)
+        dpre, G, T = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg, drop=ctx.drop)
         dgamma = _native.colsum(T)
         dbeta = _native.colsum(g)
         if tp.slice_tab is not None:
@@ -185,7 +187,7 @@ class MessageLayerFn(torch.autograd.Function):
                 Gs = _native.split_rows(G, plan.wlayout)
             dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs),
                               _raw_message(G, tp.rev, Wr, Wr2, zero_b, _native.GHF_FLAG_ZERO_DST, Gs), out=dpre)
-        return dh, dWm, dWs, db, dgamma, dbeta, None, None
+        return dh, dWm, dWs, db, dgamma, dbeta, None, None, None
 
 
 class WeightGeneratorFn(torch.autograd.Function):
@@ -196,13 +198,16 @@ class WeightGeneratorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dims, x, ls0, ls1, ls2, *params):
-        T, Hh, nh, d_in, d_out = dims
+        """dims = (T, Hh, nh, d_in, d_out[, hidden_drop, log_keep]): hidden_drop = the hidden layers' dropout masks scaled by
+        1/(1-p) ([3, nh, R, Hh]; reference weight_generator.py:96-107) and log_keep = a 1-element device tensor log(1/(1-p))."""
+        T, Hh, nh, d_in, d_out = dims[:5]
+        hidden_drop, log_keep = (dims[5], dims[6]) if len(dims) > 5 else (None, None)
         x = x.contiguous().float()
         flat = [p.detach() for p in params]
         ls = torch.cat([ls0.detach().reshape(1), ls1.detach().reshape(1), ls2.detach().reshape(1)])
-        outs = _native.weightgen_fwd(x, flat, ls, T, Hh, nh, d_in, d_out, _native.WLAYOUT_NATURAL)
-        acts = _native.weightgen_acts(x, flat, T, Hh, nh) if nh > 0 else None
-        ctx.dims, ctx.acts, ctx.n_params = dims, acts, len(params)
+        outs = _native.weightgen_fwd(x, flat, ls, T, Hh, nh, d_in, d_out, _native.WLAYOUT_NATURAL, hidden_drop=hidden_drop)
+        acts = _native.weightgen_acts(x, flat, T, Hh, nh, hidden_drop=hidden_drop) if nh > 0 else None
+        ctx.dims, ctx.acts, ctx.n_params, ctx.log_keep = dims[:5], acts, len(params), log_keep
         ctx.save_for_backward(x, ls, *outs, *params)
         return outs
 
@@ -226,7 +231,10 @@ class WeightGeneratorFn(torch.autograd.Function):
                 W = params[(k * nl + l) * 2].detach()
                 a_prev = ctx.acts[k, l - 1] if l > 0 else x
                 if l < nl - 1:
+                    # acts are post-dropout: a > 0 <=> kept and active; a kept unit's gradient carries the mask's 1/(1-p)
                     dy = _native.relu_mask(dy, ctx.acts[k, l])
+                    if ctx.log_keep is not None:
+                        dy = _native.scale_exp(dy, ctx.log_keep)
                 dparams[(k * nl + l) * 2] = _native.matmul_tn(dy, a_prev)
                 dparams[(k * nl + l) * 2 + 1] = _native.colsum(dy)
                 if l > 0 or ctx.needs_input_grad[1]:

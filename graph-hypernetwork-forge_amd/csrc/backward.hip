@@ -23,19 +23,22 @@ constexpr int BW_PER_LANE = BW_MAX_D / 64;
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ agg,
                                                        const float* __restrict__ h, const float* __restrict__ gamma, float eps,
                                                        const int32_t* __restrict__ indeg, int64_t N, int d,
-                                                       float* __restrict__ dpre, float* __restrict__ G, float* __restrict__ T) {
+                                                       float* __restrict__ dpre, float* __restrict__ G, float* __restrict__ T,
+                                                       const float* __restrict__ drop) {
     const int lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= N) return;
-    float pre[BW_PER_LANE], x[BW_PER_LANE], gg[BW_PER_LANE];
+    float pre[BW_PER_LANE], x[BW_PER_LANE], gg[BW_PER_LANE], dm[BW_PER_LANE];   // dm: the dropout mask (scaled; 1 without dropout)
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < BW_PER_LANE; ++c) {
         const int o = lane + 64 * c;
         pre[c] = x[c] = gg[c] = 0.f;
+        dm[c] = 1.f;
         if (o < d) {
             pre[c] = agg[(size_t)v * d + o] + h[(size_t)v * d + o];
-            x[c] = fmaxf(pre[c], 0.f);
+            if (drop) dm[c] = drop[(size_t)v * d + o];
+            x[c] = fmaxf(pre[c], 0.f) * dm[c];
             s += x[c];
         }
     }
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
         const int o = lane + 64 * c;
         if (o < d) {
             const float dx = rstd * (gg[c] - s1 - x[c] * s2);
-            const float dp = pre[c] > 0.f ? dx : 0.f;
+            const float dp = pre[c] > 0.f ? dx * dm[c] : 0.f;
             dpre[(size_t)v * d + o] = dp;
             G[(size_t)v * d + o] = dp * inv;
         }
@@ -381,10 +384,10 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __r
 }
 
 int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const float* gamma, float eps, const int32_t* indeg,
-                    int64_t N, int d, float* dpre, float* G, float* T, hipStream_t stream) {
+                    int64_t N, int d, float* dpre, float* G, float* T, const float* drop, hipStream_t stream) {
     GHF_REQUIRE(d >= 1 && d <= BW_MAX_D, "tail_bwd: d=%d outside [1,%d]", d, BW_MAX_D);
     if (N <= 0) return GHF_OK;
-    tail_bwd_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(g_out, agg, h, gamma, eps, indeg, N, d, dpre, G, T);
+    tail_bwd_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(g_out, agg, h, gamma, eps, indeg, N, d, dpre, G, T, drop);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

@@ -104,11 +104,11 @@ int ghf_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, 
 
 int ghf_weightgen_fwd(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                       int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout, float* hidden_ws,
-                      float* W_msg, float* W_self, float* bias, void* stream) {
+                      float* W_msg, float* W_self, float* bias, const float* hidden_drop, void* stream) {
     GHF_REQUIRE(text_emb && head_params && log_scales && log_scales[0] && log_scales[1] && log_scales[2] && hidden_ws && W_msg && bias,
                 "weightgen_fwd: null pointer argument");
     return launch_weightgen(text_emb, head_params, log_scales, R, T, Hh, num_hidden, d_in, d_out, layout,
-                            hidden_ws, W_msg, W_self, bias, (hipStream_t)stream);
+                            hidden_ws, W_msg, W_self, bias, hidden_drop, (hipStream_t)stream);
 }
 
 int ghf_text_encode_fwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
@@ -194,9 +194,9 @@ int ghf_group_edges(const int64_t* rel_id, int64_t E, int R, void* workspace, si
 }
 
 int ghf_tail_bwd(const float* grad_out, const float* agg, const float* h, const float* ln_gamma, float ln_eps,
-                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, void* stream) {
+                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, const float* drop, void* stream) {
     GHF_REQUIRE(grad_out && agg && h && ln_gamma && indeg && dpre && G && T, "tail_bwd: null pointer argument");
-    return launch_tail_bwd(grad_out, agg, h, ln_gamma, ln_eps, indeg, N, d, dpre, G, T, (hipStream_t)stream);
+    return launch_tail_bwd(grad_out, agg, h, ln_gamma, ln_eps, indeg, N, d, dpre, G, T, drop, (hipStream_t)stream);
 }
 
 size_t ghf_colsum_workspace_floats(int64_t N, int d) { return colsum_workspace_floats(N, d); }
@@ -294,9 +294,9 @@ int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* 
 }
 
 int ghf_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
-                       float* acts, void* stream) {
+                       float* acts, const float* hidden_drop, void* stream) {
     GHF_REQUIRE(text_emb && head_params && (acts || num_hidden == 0), "weightgen_acts: null pointer argument");
-    return launch_weightgen_acts(text_emb, head_params, R, T, Hh, num_hidden, acts, (hipStream_t)stream);
+    return launch_weightgen_acts(text_emb, head_params, R, T, Hh, num_hidden, acts, hidden_drop, (hipStream_t)stream);
 }
 
 int ghf_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
@@ -323,10 +323,10 @@ int ghf_score_pairs_fwd(const float* a, const float* b, const int64_t* ia, const
 }
 
 int ghf_tail_fwd(const float* agg, const float* h, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                 int64_t row0, int64_t rows, int d, float* h_out, void* stream) {
+                 int64_t row0, int64_t rows, int d, float* h_out, const float* drop, void* stream) {
     GHF_REQUIRE(agg && h && ln_gamma && ln_beta && h_out, "tail_fwd: null pointer argument");
     GHF_REQUIRE(row0 >= 0 && rows >= 0, "tail_fwd: bad row range");
-    return launch_tail(agg, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, (hipStream_t)stream);
+    return launch_tail(agg, h, ln_gamma, ln_beta, ln_eps, row0, rows, d, h_out, drop, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -133,7 +133,7 @@ constexpr int32_t SRC_MASK = (1 << SRC_BITS) - 1;
 
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
-                     float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream);
+                     float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream);
 
 int launch_score_pairs(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,
                        int64_t n, int d, float* scores, hipStream_t stream);
@@ -170,7 +170,7 @@ int launch_group_edges(const int64_t* rel, int64_t E, int R, void* ws, size_t ws
                        hipStream_t stream);
 // backward.hip
 int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const float* gamma, float eps, const int32_t* indeg,
-                    int64_t N, int d, float* dpre, float* G, float* T, hipStream_t stream);
+                    int64_t N, int d, float* dpre, float* G, float* T, const float* drop, hipStream_t stream);
 size_t colsum_workspace_floats(int64_t N, int d);
 int launch_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, hipStream_t stream);
 int launch_relu_mask(const float* X, const float* ref, int64_t n, float* out, hipStream_t stream);
@@ -200,7 +200,7 @@ int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* deg_o
                         float* h_out, void* h_split_out, int64_t n_split, int flags, hipStream_t stream);
 int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream);
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
-                          float* acts, hipStream_t stream);
+                          float* acts, const float* hidden_drop, hipStream_t stream);
 int launch_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* E, int V, int C, const float* W,
                            int T, const float* te, const float* dte, float* workspace, float* dE, float* dW, float* db,
                            hipStream_t stream);
@@ -209,6 +209,6 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
                         hipStream_t stream);
 
 int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,
-                int64_t row0, int64_t rows, int d, float* h_out, hipStream_t stream);
+                int64_t row0, int64_t rows, int d, float* h_out, const float* drop, hipStream_t stream);
 
 }  // namespace ghf

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(GEN_TPB) void message_generic_kernel(
 // K3 alone: h' = LayerNorm(ReLU(agg + h)) on rows [row0, row0+rows)
 __global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__ agg, const float* __restrict__ h,
                                                        const float* __restrict__ g, const float* __restrict__ b,
-                                                       float eps, int64_t row0, int d, float* __restrict__ h_out) {
+                                                       float eps, int64_t row0, int d, float* __restrict__ h_out,
+                                                       const float* __restrict__ drop) {
     __shared__ float red[2 * (GEN_TPB / 64)];
     const int64_t v = row0 + blockIdx.x;
     float x[GEN_MAX_PER_THREAD];
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__
     for (int c = 0; c < GEN_MAX_PER_THREAD; ++c) {
         const int o = threadIdx.x + c * GEN_TPB;
         x[c] = (o < d) ? fmaxf(agg[(size_t)v * d + o] + h[(size_t)v * d + o], 0.f) : 0.f;
+        if (drop && o < d) x[c] *= drop[(size_t)v * d + o];              // dropout between ReLU and LayerNorm (reference :293-294)
     }
     tail_store<GEN_TPB / 64>(x, d, red, g, b, eps, h_out + (size_t)v * d);
 }
@@ -244,11 +246,11 @@ int launch_message_generic(const MsgArgs& a, hipStream_t stream) {
 }
 
 int launch_tail(const float* agg, const float* h, const float* g, const float* b, float eps,
-                int64_t row0, int64_t rows, int d, float* h_out, hipStream_t stream) {
+                int64_t row0, int64_t rows, int d, float* h_out, const float* drop, hipStream_t stream) {
     GHF_REQUIRE(d >= 1 && d <= GEN_MAX_D, "tail: d=%d outside [1,%d]", d, GEN_MAX_D);
     GHF_REQUIRE(rows < (1ll << 31), "tail: too many rows per launch");
     if (rows <= 0) return GHF_OK;
-    tail_kernel<<<(unsigned)rows, GEN_TPB, 0, stream>>>(agg, h, g, b, eps, row0, d, h_out);
+    tail_kernel<<<(unsigned)rows, GEN_TPB, 0, stream>>>(agg, h, g, b, eps, row0, d, h_out, drop);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

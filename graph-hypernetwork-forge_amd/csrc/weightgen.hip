@@ -30,7 +30,8 @@ struct HeadPtrs {
 // acts (optional): every hidden layer's output, acts[((head*num_hidden + layer)*R + r)*Hh + j]  (the backward's input)
 __global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict__ text_emb, HeadPtrs P,
                                                         int R, int T, int Hh, int num_hidden,
-                                                        float* __restrict__ hidden_ws, float* __restrict__ acts) {
+                                                        float* __restrict__ hidden_ws, float* __restrict__ acts,
+                                                        const float* __restrict__ drop /* acts' layout, or NULL */) {
     __shared__ float buf[2][WG_MAX_WIDTH];
     const int r = blockIdx.x, head = blockIdx.y;
     for (int k = threadIdx.x; k < T; k += blockDim.x) buf[0][k] = text_emb[(size_t)r * T + k];
@@ -55,7 +56,10 @@ __global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict_
 #pragma unroll
             for (int u = 0; u < WG_UNROLL; ++u) {
                 const float t = wave_sum(s[u]);
-                if (lane == 0 && j0 + u < Hh) buf[cur ^ 1][j0 + u] = fmaxf(t + B[j0 + u], 0.f);
+                if (lane == 0 && j0 + u < Hh) {             // Linear -> ReLU -> Dropout (reference weight_generator.py:96-107)
+                    const float a = fmaxf(t + B[j0 + u], 0.f);
+                    buf[cur ^ 1][j0 + u] = drop ? a * drop[(((size_t)head * num_hidden + li) * R + r) * Hh + j0 + u] : a;
+                }
             }
         }
         __syncthreads();
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
 }
 
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
-                          float* acts, hipStream_t stream) {
+                          float* acts, const float* hidden_drop, hipStream_t stream) {
     GHF_REQUIRE(R > 0 && T > 0 && num_hidden >= 0 && num_hidden <= 7, "weightgen_acts: bad shape");
     GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen_acts: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
     if (num_hidden == 0) return GHF_OK;
@@ -254,7 +258,7 @@ int launch_weightgen_acts(const float* text_emb, const float* const* head_params
             P.w[h][l] = head_params[(h * nl + l) * 2 + 0];
             P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
         }
-    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, nullptr, acts);
+    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, nullptr, acts, hidden_drop);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
@@ -312,7 +316,7 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
 
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
-                     float* hidden_ws, float* W_msg, float* W_self, float* bias, hipStream_t stream) {
+                     float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream) {
     GHF_REQUIRE(R > 0 && T > 0 && d_in > 0 && d_out > 0, "weightgen: R, T, d_in, d_out must be positive");
     GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
     GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
@@ -335,7 +339,7 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
             P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
             GHF_REQUIRE(P.w[h][l] && P.b[h][l], "weightgen: null parameter pointer (head %d layer %d)", h, l);
         }
-    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, hidden_ws, nullptr);
+    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, hidden_ws, nullptr, hidden_drop);
     GHF_LAUNCH_CHECK();
 
     const int Hl = num_hidden ? Hh : T;

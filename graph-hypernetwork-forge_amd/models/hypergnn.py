@@ -190,8 +190,7 @@ class HyperGNN(nn.Module):
             raise ValueError(f"edge_index has {edge_index.size(1)} edges but edge_rel_ids has {edge_rel_ids.numel()} entries")
         if node_features.dim() != 2 or node_features.size(1) != self.node_feat_dim:
             raise ValueError(f"node_features must be [N, {self.node_feat_dim}], got {tuple(node_features.shape)}")
-        grad = wants_grad(self, node_features)
-        self._check_dropout()
+        grad = wants_grad(self, node_features) or self._dropping()
         device, N = node_features.device, node_features.size(0)
         texts = list(relation_texts)
         key = ("ids", edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
@@ -213,8 +212,7 @@ class HyperGNN(nn.Module):
                              f"edge_texts has {len(edge_texts)} entries")
         if node_features.dim() != 2 or node_features.size(1) != self.node_feat_dim:
             raise ValueError(f"node_features must be [N, {self.node_feat_dim}], got {tuple(node_features.shape)}")
-        grad = wants_grad(self, node_features)
-        self._check_dropout()
+        grad = wants_grad(self, node_features) or self._dropping()
         device = node_features.device
         plan = self.plan_for(edge_index, edge_texts, node_features.size(0), device, training=grad)
         if grad:
@@ -240,9 +238,14 @@ class HyperGNN(nn.Module):
         finally:
             _native._rs_exact_override = old
 
-    def _check_dropout(self) -> None:
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("HyperGNN: dropout in training mode is not implemented on the HIP path")
+    def _dropping(self) -> bool:
+        """Training mode with dropout > 0 (reference :293-294): the forward then takes the recorded path — the layer's tail
+        alone with a mask operand — whether or not gradients are wanted."""
+        return self.training and self.dropout > 0.0
+
+    def _draw_mask(self, shape, device) -> torch.Tensor:
+        """A dropout mask scaled by 1/(1-p), drawn with torch's generator as F.dropout does in the reference."""
+        return (torch.rand(shape, device=device) >= self.dropout).to(torch.float32) / (1.0 - self.dropout)
 
     def _forward_recorded(self, node_features: torch.Tensor, plan: GraphPlan, edge_index: torch.Tensor) -> torch.Tensor:
         """The forward when gradients are required (reference: plain autograd, demo.py:79-101): the same kernels inside
@@ -260,7 +263,8 @@ class HyperGNN(nn.Module):
         h = InputProjFn.apply(node_features, self.input_proj.weight, self.input_proj.bias)
         for gen, norm in zip(self.weight_generators, self.layer_norms):
             W_msg, W_self, bias = gen.generate_with_grad(text_embs)
-            h = MessageLayerFn.apply(h, W_msg, W_self, bias, norm.weight, norm.bias, norm.eps, plan.train)
+            drop = self._draw_mask(tuple(h.shape), device) if self._dropping() else None
+            h = MessageLayerFn.apply(h, W_msg, W_self, bias, norm.weight, norm.bias, norm.eps, plan.train, drop)
         if guard and int(flag.item()):
             self.last_range_flags = int(flag.item())
             raise RuntimeError("HyperGNN (training forward): a row of h or a relation's generated weights spans more dynamic range "
@@ -309,6 +313,9 @@ class HyperGNN(nn.Module):
         hold; the forward then ends with one 4-byte read of that flag (the only host sync of a warm forward;
         GHF_RANGE_GUARD=0 removes it) and, if it is set, runs again on the exact fp32 kernels."""
         require_inference(self, node_features, what=".forward_planned")
+        if self._dropping():
+            raise NotImplementedError("HyperGNN.forward_planned: dropout in training mode runs through forward() / forward_ids() "
+                                      "(the recorded path); call .eval() for inference")
         device = node_features.device
         x = node_features if node_features.dtype == torch.float32 else node_features.float()
         guard = guard and exchange is None and self._guarded(plan) and not torch.cuda.is_current_stream_capturing()

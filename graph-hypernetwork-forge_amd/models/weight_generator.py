@@ -93,10 +93,22 @@ class WeightGenerator(nn.Module):
     def _head_parameters(self) -> List[torch.Tensor]:
         return [p for head in HEADS for lin in self._linears(head) for p in (lin.weight, lin.bias)]
 
+    def _dropping(self) -> bool:
+        return self.training and self.dropout > 0.0 and self.num_hidden > 0
+
+    def _draw_mask(self, shape, device) -> torch.Tensor:
+        """Dropout masks scaled by 1/(1-p), drawn with torch's generator as the reference's nn.Dropout modules do."""
+        return (torch.rand(shape, device=device) >= self.dropout).to(torch.float32) / (1.0 - self.dropout)
+
     def generate_with_grad(self, text_emb: torch.Tensor):
-        """Natural-layout (W_msg, W_self, bias) recorded by autograd (backward through the C ABI)."""
+        """Natural-layout (W_msg, W_self, bias) recorded by autograd (backward through the C ABI); in training mode with
+        dropout > 0 the hidden activations are masked (reference :96-107: Linear -> ReLU -> Dropout)."""
         from ..autograd import WeightGeneratorFn
         dims = (self.text_dim, self.hidden_dim, self.num_hidden, self.d_in, self.d_out)
+        if self._dropping():
+            masks = self._draw_mask((3, self.num_hidden, text_emb.size(0), self.hidden_dim), text_emb.device)
+            log_keep = torch.full((1,), -math.log(1.0 - self.dropout), dtype=torch.float32, device=text_emb.device)
+            dims = dims + (masks, log_keep)
         return WeightGeneratorFn.apply(dims, text_emb, *(self.log_scales[h] for h in HEADS), *self._head_parameters())
 
     def _log_scale_vector(self) -> List[torch.Tensor]:
@@ -113,9 +125,7 @@ class WeightGenerator(nn.Module):
         single = text_emb.dim() == 1
         if text_emb.size(-1) != self.text_dim:
             raise ValueError(f"text_emb has last dim {text_emb.size(-1)}, expected text_dim={self.text_dim}")
-        grad = wants_grad(self, text_emb)
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("WeightGenerator: dropout in training mode is not implemented on the HIP path")
+        grad = wants_grad(self, text_emb) or self._dropping()
         x = text_emb.unsqueeze(0) if single else text_emb
         W_msg, W_self, bias = self.generate_with_grad(x.float()) if grad else self.generate(x.float())
         out = {"W_msg": W_msg, "W_self": W_self, "bias": bias}

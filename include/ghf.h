@@ -105,11 +105,15 @@ int ghf_plan_build(const int64_t* edge_index /* [2,E] row 0 = src, row 1 = dst *
  *  hidden_ws:   scratch for hidden activations, >= 3*2*R*max(Hh,T) floats.
  *  layout NATURAL: W_msg,W_self [R,d_in,d_out], bias [R,d_out] (any d_in,d_out).
  *  layout FRAG16:  requires d_in == d_out == d, d % 16 == 0; W_msg is the combined
- *                  fragment buffer of 2*R*d*d floats and W_self must be NULL. */
+ *                  fragment buffer of 2*R*d*d floats and W_self must be NULL.
+ *  hidden_drop:    training with dropout > 0 (the reference's Linear -> ReLU -> Dropout, weight_generator.py:96-107): the masks,
+ *                  already scaled by 1/(1-p), as floats [3 heads][num_hidden][R][Hh] (ghf_weightgen_acts' layout), multiplied
+ *                  into every hidden activation; NULL: none.  The caller draws them (the reference draws them with torch's
+ *                  generator; so does the Python mirror). */
 int ghf_weightgen_fwd(const float* text_emb /* [R,T] */, const float* const* head_params,
                       const float* const* log_scales /* [3] host array of device pointers */, int R, int T, int Hh, int num_hidden,
                       int d_in, int d_out, int layout, float* hidden_ws,
-                      float* W_msg, float* W_self, float* bias, void* stream);
+                      float* W_msg, float* W_self, float* bias, const float* hidden_drop /* or NULL */, void* stream);
 
 /* ---- text encoder ------------------------------------------------------------------
  * Replaces models/hypergnn.py:39-81 (TextEncoder) for U strings at once:
@@ -186,10 +190,11 @@ int ghf_set_range_flag(int32_t* device_word);
 
 /* ---- K3 alone -------------------------------------------------------------------------
  * Replaces models/hypergnn.py:288-296 on rows [row0,row0+rows): agg already holds
- * out_v (GHF_FLAG_NO_TAIL output, e.g. after a cross-GPU reduction). */
+ * out_v (GHF_FLAG_NO_TAIL output, e.g. after a cross-GPU reduction).  drop (training with dropout > 0, :293-294): the
+ * mask, scaled by 1/(1-p), multiplied in between ReLU and LayerNorm; ghf_tail_bwd takes the same mask. */
 int ghf_tail_fwd(const float* agg /* [N,d] */, const float* h /* [N,d] */,
                  const float* ln_gamma, const float* ln_beta, float ln_eps,
-                 int64_t row0, int64_t rows, int d, float* h_out, void* stream);
+                 int64_t row0, int64_t rows, int d, float* h_out, const float* drop /* [N,d] or NULL */, void* stream);
 
 /* ---- wide hidden sizes: the relation-stationary message layer (csrc/message_rs.hip) ---------------------------------
  * For d % 128 == 0, 128 <= d <= 1024 (ghf_message_rs_supported; BASELINE config 5, and d = 128 with many relations).  Same statement as
@@ -249,7 +254,7 @@ size_t ghf_group_workspace_bytes(int64_t E);
 int ghf_group_edges(const int64_t* rel_id, int64_t E, int R, void* workspace, size_t workspace_bytes,
                     int64_t* perm, int64_t* goff, void* stream);
 int ghf_tail_bwd(const float* grad_out, const float* agg, const float* h, const float* ln_gamma, float ln_eps,
-                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, void* stream);
+                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, const float* drop /* [N,d] or NULL */, void* stream);
 size_t ghf_colsum_workspace_floats(int64_t N, int d);
 int ghf_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, void* stream);
 int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void* stream);
@@ -277,7 +282,7 @@ int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* 
 /* Hidden activations of the weight generator's three heads (what its backward needs besides the outputs):
  * acts[head][layer][r][Hh], layer = 0 .. num_hidden-1 (post-ReLU).  Same head_params as ghf_weightgen_fwd. */
 int ghf_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
-                       float* acts, void* stream);
+                       float* acts, const float* hidden_drop /* or NULL */, void* stream);
 /* Backward of ghf_text_encode_fwd: given te = its output and dte = dL/dte, writes dL/dchar_emb [V,C], dL/dW [T,C],
  * dL/db [T] (overwritten, fixed summation order).  workspace: 2*U*C + U*T floats. */
 int ghf_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,

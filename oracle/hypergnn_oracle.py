@@ -81,10 +81,12 @@ def _head_linears(params: Params, prefix: str, head: str) -> List[Tuple[str, str
 
 
 def weight_generator(params: Params, prefix: str, text_emb, d_in: int, d_out: int,
-                     dtype=torch.float32) -> Dict[str, torch.Tensor]:
+                     dtype=torch.float32, drop=None) -> Dict[str, torch.Tensor]:
     """reference weight_generator.py:120-143 (eval mode: Dropout is identity).
 
     ``text_emb`` [T] or [B,T] -> {"W_msg": (B,)d_in x d_out, "W_self": same, "bias": (B,)d_out}.
+    Training mode with dropout p > 0 (:96-107, Linear -> ReLU -> Dropout): ``drop`` [3 heads, hidden layers, B, hidden] holds the
+    masks nn.Dropout would have drawn, already scaled by 1/(1-p) (nn.Dropout: y = x * mask / (1-p)).
     """
     x = _t(text_emb, dtype)
     single = x.dim() == 1                                  # :132-134
@@ -98,6 +100,8 @@ def weight_generator(params: Params, prefix: str, text_emb, d_in: int, d_out: in
             z = z @ _t(params[wk], dtype).t() + _t(params[bk], dtype)
             if li + 1 < len(lin):
                 z = torch.relu(z)
+                if drop is not None:
+                    z = z * _t(drop[_HEADS.index((head, rank))][li], dtype)
         scale = _t(params[f"{prefix}log_scales.{head}"], dtype).exp()   # :139
         shape = (d_in, d_out) if rank == 2 else (d_out,)
         w = z.view(x.size(0), *shape) * scale              # :140
@@ -172,11 +176,14 @@ def message_passing_factorised(h: torch.Tensor, edge_index: torch.Tensor, rel: t
 
 
 def layer_tail(h_new: torch.Tensor, h: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-               eps: float = LN_EPS) -> torch.Tensor:
-    """reference hypergnn.py:288-296 in eval mode: residual, ReLU, LayerNorm (biased variance)."""
+               eps: float = LN_EPS, drop=None) -> torch.Tensor:
+    """reference hypergnn.py:288-296: residual, ReLU, [training: dropout, ``drop`` = the mask scaled by 1/(1-p)], LayerNorm
+    (biased variance)."""
     if h_new.shape == h.shape:                             # :289-290
         h_new = h_new + h
     h_new = torch.relu(h_new)                              # :291
+    if drop is not None:                                   # :293-294  F.dropout(h_new, p) = h_new * mask / (1-p)
+        h_new = h_new * _t(drop, h_new.dtype)
     return torch.nn.functional.layer_norm(h_new, (h_new.size(-1),), gamma, beta, eps)   # :296
 
 
@@ -195,8 +202,9 @@ def num_layers_of(params: Params) -> int:
 
 def forward(params: Params, node_features, edge_index, edge_texts: Sequence[str], *,
             variant: str = "reference", dtype=torch.float32,
-            return_intermediates: bool = False):
-    """HyperGNN.forward in eval mode.
+            return_intermediates: bool = False, drop=None):
+    """HyperGNN.forward in eval mode — or, with ``drop`` = {"layers": [mask [N,d] per layer], "gen": [masks [3,nh,R,Hh] per
+    layer]} (each scaled by 1/(1-p)), in training mode with the dropout masks the reference would have drawn.
 
     variant "reference": per-edge weight gather + the reference op sequence
     (hypergnn.py:281-286); "factorised": per-relation loop, no [E,d,d].
@@ -215,7 +223,8 @@ def forward(params: Params, node_features, edge_index, edge_texts: Sequence[str]
     text_embs = text_encode(params, unique, dtype)         # :270
     inter = {"h0": h, "text_embs": text_embs, "rel_ids": rel}
     for l in range(num_layers_of(params)):                 # :272
-        uw = weight_generator(params, f"weight_generators.{l}.", text_embs, d, d, dtype)   # :278
+        uw = weight_generator(params, f"weight_generators.{l}.", text_embs, d, d, dtype,   # :278
+                              drop=None if drop is None else drop["gen"][l])
         if variant == "reference":
             h_new = message_passing_reference_shaped(      # :281-286
                 h, ei, uw["W_msg"][rel], uw["W_self"][rel], uw["bias"][rel])
@@ -225,7 +234,7 @@ def forward(params: Params, node_features, edge_index, edge_texts: Sequence[str]
             raise ValueError(variant)
         gamma = _t(params[f"layer_norms.{l}.weight"], dtype)
         beta = _t(params[f"layer_norms.{l}.bias"], dtype)
-        h = layer_tail(h_new, h, gamma, beta)              # :288-296
+        h = layer_tail(h_new, h, gamma, beta, drop=None if drop is None else drop["layers"][l])   # :288-296
         inter[f"W_msg{l}"], inter[f"W_self{l}"], inter[f"bias{l}"] = uw["W_msg"], uw["W_self"], uw["bias"]
         inter[f"h{l + 1}"] = h
     return (h, inter) if return_intermediates else h

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     if (p_ghf_split_rows_bytes(10, 128, GHF_WLAYOUT_SPLIT2H) != (size_t)10 * 128 * 4 + 40) return 8;
     if (!p_ghf_edge_outer_supported(128) || p_ghf_edge_outer_supported(20)) return 9;
     /* argument errors come back as a code plus a thread-local message, never as a fault */
-    if (p_ghf_tail_fwd(NULL, NULL, NULL, NULL, 1e-5f, 0, 1, 8, NULL, NULL) != -1) return 10;
+    if (p_ghf_tail_fwd(NULL, NULL, NULL, NULL, 1e-5f, 0, 1, 8, NULL, NULL, NULL) != -1) return 10;
     if (!strstr(p_ghf_last_error(), "null")) return 11;
     printf("ok %d\n", p_ghf_abi_version());
     dlclose(lib);

@@ -100,6 +100,48 @@ def run_wg_case(c: cases.WGCase) -> dict:
     return rec
 
 
+# Training mode with dropout (reference hypergnn.py:293-294, weight_generator.py:96-107): the reference draws its masks from
+# torch's generator; on the CPU F.dropout / nn.Dropout are `noise = empty_like(x).bernoulli_(1 - p) / (1 - p); x * noise`, so
+# the same seed and the same sequence of shapes reproduce the masks.  Stored: the masks (scaled) and the output; checked
+# here: the oracle, given those masks, reproduces the reference's training-mode output.
+DROPOUT_CASE = dict(T=32, F=16, d=32, L=2, p=0.25, N=300, E=2500, R=7, seed=4711, torch_seed=1234)
+
+
+def run_dropout_case() -> dict:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from graph_hypernetwork_forge_amd import synth
+    from oracle import hypergnn_oracle as O
+    c = DROPOUT_CASE
+    g = synth.make_kg(c["N"], c["E"], c["R"], c["F"], seed=c["seed"], kind="powerlaw")
+    texts = g.edge_texts()
+    params = synth.hypergnn_params(c["T"], c["F"], c["d"], c["L"], seed=c["seed"], dropout=c["p"], log_scale=-1.0, randomize_ln=True)
+    model = HyperGNN(text_dim=c["T"], node_feat_dim=c["F"], hidden_dim=c["d"], num_layers=c["L"], dropout=c["p"])
+    load_params(model, params)
+    model.train()
+    x, ei = torch.from_numpy(g.node_features), torch.from_numpy(g.edge_index)
+    torch.manual_seed(c["torch_seed"])
+    with torch.no_grad():
+        out = model(x, ei, texts)
+    R = len(dict.fromkeys(texts))
+    hh, keep = max(64, 2 * c["T"]), 1.0 - c["p"]
+    torch.manual_seed(c["torch_seed"])
+    gen_masks, layer_masks = [], []
+    for _ in range(c["L"]):                                 # the reference's draw order: three heads x two hidden layers, then the layer
+        gen_masks.append(torch.stack([torch.stack([torch.empty(R, hh).bernoulli_(keep) / keep for _li in range(2)]) for _h in range(3)]))
+        layer_masks.append(torch.empty(c["N"], c["d"]).bernoulli_(keep) / keep)
+    ours = O.forward(params, g.node_features, g.edge_index, texts, variant="reference", drop={"layers": layer_masks, "gen": gen_masks})
+    assert torch.allclose(ours, out, rtol=1e-5, atol=1e-6), float((ours - out).abs().max())
+    model.eval()
+    with torch.no_grad():
+        assert not torch.allclose(model(x, ei, texts), out, atol=1e-2), "the masks must matter"
+    print(f"  g_dropout: reference training-mode forward reproduced by the oracle with replayed masks "
+          f"(max diff {float((ours - out).abs().max()):.2e})", flush=True)
+    rec = {"out": out.numpy(), "params_sha256": np.array(cases.params_digest(params))}
+    for l in range(c["L"]):
+        rec[f"gen_mask{l}"], rec[f"layer_mask{l}"] = gen_masks[l].numpy(), layer_masks[l].numpy()
+    return rec
+
+
 def main(argv) -> None:
     torch.set_num_threads(8)
     only = argv[1:] or None
@@ -121,6 +163,8 @@ def main(argv) -> None:
             for k, v in run_wg_case(c).items():
                 recs[f"{c.name}/{k}"] = v
         np.savez(os.path.join(HERE, "wg_cases.npz"), **recs)
+    if only is None or "g_dropout" in only:
+        np.savez_compressed(os.path.join(HERE, "g_dropout.npz"), **run_dropout_case())
 
 
 if __name__ == "__main__":

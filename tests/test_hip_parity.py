@@ -655,6 +655,59 @@ def test_model_backward_matches_autograd_of_the_oracle(name, N, E, R, kind):
         assert_close(model(x.detach(), torch.from_numpy(ei).to(DEV), texts).cpu().numpy(), out.detach().cpu().numpy(), "eval")
 
 
+def test_training_mode_dropout_matches_reference_and_its_gradients(golden_dir, monkeypatch):
+    """train() with dropout 0.25 (reference hypergnn.py:293-294, weight_generator.py:96-107): with the masks the reference drew
+    (tests/golden/g_dropout.npz) handed to the HIP path in place of its own draws, the forward equals the reference's
+    training-mode output and every gradient equals float64 autograd through the oracle with the same masks; with its own
+    draws the masks have the right rate and scale; eval() is untouched."""
+    from test_oracle_golden import DROPOUT_CASE as c, dropout_case
+    from graph_hypernetwork_forge_amd.models.weight_generator import WeightGenerator as WG
+    params, g, texts, drop, want = dropout_case(golden_dir)
+    model = HyperGNN(c["T"], c["F"], c["d"], c["L"], dropout=c["p"]).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    model.train()
+    x, ei = torch.from_numpy(g.node_features).to(DEV), torch.from_numpy(g.edge_index).to(DEV)
+    queue = {"gen": [m.to(DEV) for m in drop["gen"]], "layers": [m.to(DEV) for m in drop["layers"]]}
+    seen = []
+
+    def gen_mask(self, shape, device):
+        seen.append(("gen", tuple(shape)))
+        return queue["gen"].pop(0)
+
+    def layer_mask(self, shape, device):
+        seen.append(("layer", tuple(shape)))
+        return queue["layers"].pop(0)
+    with monkeypatch.context() as mp_:
+        mp_.setattr(WG, "_draw_mask", gen_mask)
+        mp_.setattr(HyperGNN, "_draw_mask", layer_mask)
+        out = model(x, ei, texts)
+        assert seen == [("gen", tuple(drop["gen"][0].shape)), ("layer", (c["N"], c["d"]))] * c["L"], "the reference's draw order"
+        assert_close(out.detach().cpu().numpy(), want, "training-mode forward with the reference's masks")
+        gout = synth.normal(5, "gout", (c["N"], c["d"]))
+        (out * torch.from_numpy(gout).to(DEV)).sum().backward()
+    ref_p = {k: torch.from_numpy(np.ascontiguousarray(v)).double().requires_grad_(True) for k, v in params.items()}
+    ref = O.forward(ref_p, torch.from_numpy(g.node_features).double(), g.edge_index, texts, variant="factorised",
+                    dtype=torch.float64, drop=drop)
+    (ref * torch.from_numpy(gout).double()).sum().backward()
+    for k, p_ in model.named_parameters():
+        assert p_.grad is not None, f"no gradient on {k}"
+        _grad_check(k, p_.grad.cpu().numpy(), ref_p[k].grad.numpy())
+    # its own draws: Bernoulli(1 - p) / (1 - p), different every call; under no_grad too (the reference drops whenever training)
+    drawn = model._draw_mask((4000, c["d"]), DEV)
+    assert all(v == 0.0 or abs(v - 1 / (1 - c["p"])) < 1e-6 for v in np.unique(drawn.cpu().numpy()).tolist())
+    assert abs(float((drawn > 0).float().mean()) - (1 - c["p"])) < 0.02
+    with torch.no_grad():
+        a, b = model(x, ei, texts), model(x, ei, texts)
+    assert not torch.allclose(a, b, atol=1e-3) and not np.allclose(a.cpu().numpy(), want, atol=1e-2)
+    with pytest.raises(NotImplementedError):
+        model.forward_planned(x, model.plan_for(ei, texts, c["N"], DEV))
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x, ei, texts), model(x, ei, texts)
+    assert torch.equal(e1, e2)
+    assert_close(e1.cpu().numpy(), O.forward(params, g.node_features, g.edge_index, texts, variant="factorised").numpy(), "eval")
+
+
 def test_relu_kink_instance_lands_on_one_side_of_the_float64_oracle():
     """The waived case of the round-1 fuzz sweep (tests/fuzz_parity.py --seed 33, case 22: d=128 N=750 E=13290 R=18 L=3),
     pinned.  One hidden pre-activation of generator 0's W_msg head — relation 0, unit 26 — is +9.0e-9 in float64 against a

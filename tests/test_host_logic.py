@@ -57,7 +57,7 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.ghf_plan_max_chunks(1000, 5000, 7, 1, 0) == 0
     assert lib.ghf_plan_max_items(1000, 5000, 7, 216, 48, 128) >= 5
     assert lib.ghf_input_proj_fwd(None, None, None, 4, 4, 4, None, None, 0, None) == -1
-    assert lib.ghf_tail_fwd(None, None, None, None, 1e-5, 0, 1, 8, None, None) == -1
+    assert lib.ghf_tail_fwd(None, None, None, None, 1e-5, 0, 1, 8, None, None, None) == -1
 
 
 def test_message_config_is_safe_as_the_first_call_of_a_process():

@@ -107,3 +107,33 @@ def test_isolated_nodes_get_relu_layernorm_of_h():
     assert torch.count_nonzero(out[[0, 1, 3, 4, 5]]) == 0
     ref = O.message_passing_reference_shaped(h, ei, Wm[rel], Ws[rel], b[rel])
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
+DROPOUT_CASE = dict(T=32, F=16, d=32, L=2, p=0.25, N=300, E=2500, R=7, seed=4711)      # tests/golden/make_golden.py
+
+
+def dropout_case(golden_dir):
+    """(params, graph, texts, {"layers": [...], "gen": [...]} masks, reference training-mode output) of g_dropout.npz."""
+    from graph_hypernetwork_forge_amd import synth
+    c = DROPOUT_CASE
+    g = synth.make_kg(c["N"], c["E"], c["R"], c["F"], seed=c["seed"], kind="powerlaw")
+    params = synth.hypergnn_params(c["T"], c["F"], c["d"], c["L"], seed=c["seed"], dropout=c["p"], log_scale=-1.0, randomize_ln=True)
+    f = _load(golden_dir, "g_dropout")
+    _check_digest(f, params)
+    drop = {"layers": [torch.from_numpy(f[f"layer_mask{l}"]) for l in range(c["L"])],
+            "gen": [torch.from_numpy(f[f"gen_mask{l}"]) for l in range(c["L"])]}
+    return params, g, g.edge_texts(), drop, f["out"]
+
+
+@pytest.mark.parametrize("variant", ["reference", "factorised"])
+def test_training_mode_dropout_matches_reference(golden_dir, variant):
+    """The reference in train() mode with dropout 0.25 under a fixed torch seed: its masks were replayed from the same seed
+    when the fixture was made (make_golden.py: run_dropout_case) and are stored with its output; the oracle, given the masks,
+    reproduces it (reference hypergnn.py:293-294, weight_generator.py:96-107)."""
+    params, g, texts, drop, want = dropout_case(golden_dir)
+    for m in drop["layers"] + drop["gen"]:
+        vals = np.unique(m.numpy())
+        assert all(v == 0.0 or abs(v - 1 / 0.75) < 1e-6 for v in vals.tolist()) and 0.6 < float((m > 0).float().mean()) < 0.9
+    out = O.forward(params, g.node_features, g.edge_index, texts, variant=variant, drop=drop)
+    assert_close(out.numpy(), want, f"g_dropout/{variant}")
+    assert not np.allclose(O.forward(params, g.node_features, g.edge_index, texts, variant=variant).numpy(), want, atol=1e-2)
