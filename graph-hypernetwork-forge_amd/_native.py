@@ -179,6 +179,41 @@ def range_flag(device) -> torch.Tensor:
     return _range_flag
 
 
+class RangeFlagRead:
+    """The guard word read EARLY: every bit a forward on the block kernels can raise is raised before its last layer is
+    launched (rows are cut by the input projection and by the tails of the layers before the last; weights are packed
+    before their layer starts), so the 4-byte copy is enqueued on a side stream behind an event recorded just before that
+    launch, and the host waits for the copy while the GPU runs the last layer — it is back in time to enqueue the next
+    forward, where a read at the very end left the GPU idle for the host's launch latency (C3: ~0.3 ms per forward)."""
+    _host: Optional[torch.Tensor] = None
+    _stream = None
+
+    def __init__(self, flag: torch.Tensor) -> None:
+        cls = RangeFlagRead
+        if cls._host is None:
+            cls._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if cls._stream is None or cls._stream.device != flag.device:
+            cls._stream = torch.cuda.Stream(device=flag.device)
+        self.flag, self.done = flag, None
+
+    def arm(self) -> None:
+        """Call on the forward's stream right before its last layer is enqueued."""
+        cls = RangeFlagRead
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.flag.device))
+        cls._stream.wait_event(ev)
+        with torch.cuda.stream(cls._stream):
+            cls._host.copy_(self.flag, non_blocking=True)
+            self.done = torch.cuda.Event()
+            self.done.record(cls._stream)
+
+    def value(self) -> int:
+        if self.done is None:                       # never armed (a path without an early point): a plain read
+            return int(self.flag.item())
+        self.done.synchronize()
+        return int(RangeFlagRead._host[0])
+
+
 def message_config(d: int, kernel: Optional[str] = None) -> Tuple[int, int, int, int]:
     """(block_nodes, weight layout, chunk_rows, split_chunks) of the message kernel for hidden size d; `kernel` names one
     as GHF_KERNEL would ("pp": the exact fp32-MFMA kernel, "generic", ...)."""

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -282,17 +284,23 @@ class HyperGNN(nn.Module):
             return [gen.generate(text_embs, layout) for gen in self.weight_generators], [None] * self.num_layers
         dev = text_embs.device
         main = torch.cuda.current_stream(dev)
-        if self._wg_stream is None or self._wg_stream.device != dev:
-            self._wg_stream = torch.cuda.Stream(device=dev)
-        side = self._wg_stream
-        if after is not None:
-            side.wait_event(after)                                    # an event recorded once text_embs was enqueued
-        else:
-            side.wait_stream(main)                                    # text_embs, and the previous call's readers
+        # one side stream per layer: the generators are independent chains of small latency-bound kernels, so side by side
+        # all of them finish in the shadow of the input projection; in ONE side stream the later layers' kernels ran beside
+        # the first message launch, which holds every CU's LDS — they trickled in as workgroups retired (0.3 ms each instead
+        # of 0.05) and cost that launch 6 %
+        nside = max(1, int(os.environ.get("GHF_WG_STREAMS", str(self.num_layers))))
+        if self._wg_stream is None or self._wg_stream[0].device != dev or len(self._wg_stream) != nside:
+            self._wg_stream = [torch.cuda.Stream(device=dev) for _ in range(nside)]
         weights, ready = [], []
         try:
-            torch.cuda.set_stream(side)
-            for gen in self.weight_generators:
+            for l, gen in enumerate(self.weight_generators):
+                side = self._wg_stream[l % nside]
+                if l < nside:
+                    if after is not None:
+                        side.wait_event(after)                            # an event recorded once text_embs was enqueued
+                    else:
+                        side.wait_stream(main)                            # text_embs, and the previous call's readers
+                torch.cuda.set_stream(side)
                 weights.append(gen.generate(text_embs, layout))
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -319,18 +327,24 @@ class HyperGNN(nn.Module):
         device = node_features.device
         x = node_features if node_features.dtype == torch.float32 else node_features.float()
         guard = guard and exchange is None and self._guarded(plan) and not torch.cuda.is_current_stream_capturing()
+        reader = None
         if guard:
             flag = _native.range_flag(device)
             flag.zero_()
-        out = self._forward_planned(x, plan, exchange)
+            reader = _native.RangeFlagRead(flag)
+        early = reader is not None and os.environ.get("GHF_GUARD_EARLY", "1") != "0"           # (0: read at the end, for A/B)
+        out = self._forward_planned(x, plan, exchange, before_last=reader.arm if early else None)
         if guard:
-            bits = int(flag.item())
+            bits = reader.value()
             self.last_range_flags = bits
             if bits:
                 return self._forward_exact(x, plan, bits)
         return out
 
-    def _forward_planned(self, x: torch.Tensor, plan: GraphPlan, exchange=None) -> torch.Tensor:
+    def _forward_planned(self, x: torch.Tensor, plan: GraphPlan, exchange=None, before_last=None) -> torch.Tensor:
+        """before_last(): called right before the last layer is enqueued (nothing after that point raises a range-guard
+        bit on the block kernels: _native.RangeFlagRead); the wide-row path cuts rows inside its last layer and is not
+        given an early point."""
         device = x.device
         if plan.block_nodes == 1 and _native.rs_supported(self.hidden_dim):
             return self._forward_wide(x, plan, exchange)
@@ -355,6 +369,8 @@ class HyperGNN(nn.Module):
             if ready[l] is not None:
                 main.wait_event(ready[l])
             W, W_self, bias = weights[l]
+            if l == last and before_last is not None:
+                before_last()
             fused = split and exchange is None and l < last
             _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(),
                                       norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo,

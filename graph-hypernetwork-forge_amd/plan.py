@@ -85,11 +85,12 @@ RS_RUN_MAX = 256            # edges per row of a run plan: longer (destination, 
 RS_RUNS_MAX_SHARE = 0.75    # runs pay when they leave at most this share of the rows (they cost one more pass over the sources)
 RS_HUB_ROWS = 4096           # a destination with more rows than this is summed in chunks of this many by whole workgroups
 SRC_MASK = 0x0FFFFFFF
-# d = 64: the two-fp16-piece kernel (message_bx<64>) is 1.4x the exact fp32-MFMA kernel per edge, but its forward ends with the
-# range guard's read of a device word (ghf.h: ghf_set_range_flag) — a host sync.  A forward of a few hundred microseconds is
-# bound by the host's launches, which that sync stops from running ahead: at BASELINE config 2 (1 M edges) the kernel went
-# 0.237 -> 0.207 ms and the forward 0.67 -> 0.81 ms.  Below this many edges the exact kernel (no guard) is the default.
-D64_PIECES_MIN_EDGES = 4_000_000
+# d = 64: the two-fp16-piece kernel (message_bx<64>) is 1.4x the exact fp32-MFMA kernel per edge, but its forward carries the
+# range guard's read of a device word (ghf.h: ghf_set_range_flag) — a host sync, which a forward of a few hundred microseconds
+# (bound by the host's launches) feels.  With the read at the END of the forward BASELINE config 2 (1 M edges) went from
+# 0.67 to 0.81 ms on the faster kernel; read before the last layer (_native.RangeFlagRead) it is 0.65 ms against 0.66.  Below
+# this many edges — graphs whose whole forward is a handful of launch latencies — the exact kernel (no guard) stays the default.
+D64_PIECES_MIN_EDGES = 500_000
 
 
 def plan_config(d: int, E: int) -> Tuple[int, int, int, int]:
