@@ -5,27 +5,44 @@
 // and uses element s in step s of v_mfma_f32_16x16x4_f32 (a k-permutation shared by A and
 // B; exact fp32 fma chain).  A wave owns IP_MT*16 rows and all d output columns, so each
 // W_in fragment loaded from L1/L2 is reused IP_MT times and x is read from HBM once.
+// The product is formed TRANSPOSED (W_in's fragment as the A operand, x's as B): a lane then holds four CONSECUTIVE output
+// columns of one row, so h0 goes out in 16-byte stores and its fp16 pieces in 8-byte stores (with x as the A operand a
+// lane held one column of four rows: 4- and 2-byte stores, 0.61 ms at C3 against 0.44 without the pieces).
 // Shapes the tile does not cover (F % 16, d % 16, d > 256) take a vector-ALU kernel.
 #include "common.h"
 
 namespace ghf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ip_f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int IP_MT = 2;       // m-tiles (16 rows each) per wave
 
-// SPLIT: also write the rows in GHF_WLAYOUT_SPLIT2H form (ghf_split_rows) for the first message layer's gathers:
-// a row lives in the 16 lanes of one DPP row, so its largest magnitude is four DPP steps away.
-template <int NT, bool SPLIT>  // n-tiles of 16 output columns: d = 16*NT
+// SPLIT: also write the rows in GHF_WLAYOUT_SPLIT2H form (ghf_split_rows) for the first message layer's gathers: a row
+// lives in the four lanes {c16, c16 + 16, c16 + 32, c16 + 48}, so its largest magnitude is two lane exchanges away.
+// WLDS: W_in staged once per workgroup in LDS (rows padded by four floats: the 16 lanes of a fragment read then cover
+// every bank once) and the workgroup walks row tiles — with W_in's fragments coming from L2 one column tile ahead the
+// matrix pipe was 48 % busy (0.44 ms at C3 for 33 GFLOP)
+template <int NT, bool SPLIT, bool WLDS>  // n-tiles of 16 output columns: d = 16*NT
 __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ bias, int64_t N, int F,
                                                               float* __restrict__ h0, char* __restrict__ h_split,
                                                               int32_t* __restrict__ range_flag) {
     constexpr int D = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) float ip_w[];      // WLDS: [D][F + 4]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane >> 4, c16 = lane & 15;
-    const int64_t row_base = ((int64_t)blockIdx.x * 4 + wv) * (16 * IP_MT);
-    if (row_base >= N) return;
+    const int wp = WLDS ? F + 4 : F;                                  // pitch of a W row where the fragments are read
+    if (WLDS) {
+        for (int i = threadIdx.x; i < D * (F >> 2); i += 256) {
+            const int row = i / (F >> 2), c4 = i - row * (F >> 2);
+            *(f32x4*)(ip_w + (size_t)row * wp + 4 * c4) = *(const f32x4*)(W + (size_t)row * F + 4 * c4);
+        }
+        __syncthreads();
+    }
+    const int64_t ntiles = (N + 16 * IP_MT - 1) / (16 * IP_MT);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += WLDS ? (int64_t)gridDim.x * 4 : ntiles) {
+    const int64_t row_base = tile * (16 * IP_MT);
 
     const float* arow[IP_MT];
 #pragma unroll
@@ -34,92 +51,103 @@ __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __res
         if (r >= N) r = N - 1;                           // clamp: rows past N are computed but not stored
         arow[m] = x + (size_t)r * F + 4 * q;
     }
-    f32x4 acc[IP_MT][NT];
+    f32x4 acc[IP_MT][NT];                                // [row tile][column tile]: element s = column 16t + 4q + s of row c16
 #pragma unroll
-    for (int m = 0; m < IP_MT; ++m)
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 bv = *(const f32x4*)(bias + 16 * t + 4 * q);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float bv = bias[16 * t + c16];         // D column = lane & 15
-            acc[m][t] = (f32x4){bv, bv, bv, bv};
-        }
-    // x fragments one 16-wide k-slice ahead, W fragments one column tile ahead: the MFMAs of a tile (256 cycles) cover
-    // both loads (W_in is L1/L2 resident; x streams from HBM once)
+        for (int m = 0; m < IP_MT; ++m) acc[m][t] = bv;
+    }
+    // x fragments one 16-wide k-slice ahead (x streams from HBM once); W fragments from LDS (or, shapes too big for it, L2)
     const int NJ = F >> 4;
-    const float* __restrict__ wrow = W + (size_t)c16 * F + 4 * q;
+    const float* __restrict__ wrow = (WLDS ? ip_w : W) + (size_t)c16 * wp + 4 * q;
     f32x4 a[IP_MT], an[IP_MT];
 #pragma unroll
     for (int m = 0; m < IP_MT; ++m) a[m] = *(const f32x4*)(arow[m]);
-    f32x4 b = *(const f32x4*)(wrow);
+    // column tiles in groups of TG: the MFMAs of a group go round its TG * IP_MT accumulators, so that consecutive ones are
+    // independent (two chains per wave — s inside one accumulator — left the pipe waiting for results: 52 % busy)
+    constexpr int TG = NT % 4 == 0 ? 4 : (NT % 2 == 0 ? 2 : 1);
     for (int j = 0; j < NJ; ++j) {
         const int jn = j + 1 < NJ ? j + 1 : j;            // (the last slice is read twice: no branch around the loads)
 #pragma unroll
         for (int m = 0; m < IP_MT; ++m) an[m] = *(const f32x4*)(arow[m] + 16 * jn);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 bn = t + 1 < NT ? *(const f32x4*)(wrow + (size_t)16 * (t + 1) * F + 16 * j)
-                                        : *(const f32x4*)(wrow + 16 * jn);
+        for (int t0 = 0; t0 < NT; t0 += TG) {
+            f32x4 b[TG];
+#pragma unroll
+            for (int u = 0; u < TG; ++u) b[u] = *(const f32x4*)(wrow + (size_t)16 * (t0 + u) * wp + 16 * j);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int m = 0; m < IP_MT; ++m)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], b[s], acc[m][t], 0, 0, 0);
-            b = bn;
+                for (int u = 0; u < TG; ++u)
+#pragma unroll
+                    for (int m = 0; m < IP_MT; ++m)      // D[i = output column][j = row] = sum_k W[i][k] x[j][k]
+                        acc[m][t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][s], a[m][s], acc[m][t0 + u], 0, 0, 0);
         }
 #pragma unroll
         for (int m = 0; m < IP_MT; ++m) a[m] = an[m];
     }
-    // D: lane holds rows 4q + reg, column 16t + c16
+    auto across_q = [&](float v, bool take_max) -> float {     // over the four lanes that hold one row
 #pragma unroll
-    for (int m = 0; m < IP_MT; ++m)
+        for (int off = 16; off < 64; off <<= 1) {
+            const float o = __shfl_xor(v, off);
+            v = take_max ? fmaxf(v, o) : v + o;
+        }
+        return v;
+    };
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int64_t r = row_base + 16 * m + 4 * q + s;
-            float v[NT];
+    for (int m = 0; m < IP_MT; ++m) {
+        const int64_t r = row_base + 16 * m + c16;
+        f32x4 v[NT];
+        float mx = 0.f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = fmaxf(acc[m][t][s], 0.f);
-            float up = 1.f;
-            if (SPLIT) {                                  // (all lanes take part in the reduction)
-                float mx = 0.f;
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) mx = fmaxf(mx, v[t]);
-                mx = fmaxf(mx, dpp_take<0xB1, 0xF>(mx));
-                mx = fmaxf(mx, dpp_take<0x4E, 0xF>(mx));
-                mx = fmaxf(mx, dpp_take<0x141, 0xF>(mx));
-                mx = fmaxf(mx, dpp_take<0x140, 0xF>(mx));  // every lane of the 16 holds the row's maximum
-                const int sh = split2h_shift(mx);
-                up = pow2f(sh);
-                if (r < N && c16 == 0) *(float*)(h_split + (size_t)N * (4 * D) + (size_t)r * 4) = pow2f(-sh);
+            for (int s = 0; s < 4; ++s) {
+                v[t][s] = fmaxf(acc[m][t][s], 0.f);
+                mx = fmaxf(mx, v[t][s]);
             }
-            if (r < N) {
+        float up = 1.f;
+        if (SPLIT) {                                      // (all lanes take part in the reduction)
+            const int sh = split2h_shift(across_q(mx, true));
+            up = pow2f(sh);
+            if (r < N && q == 0) *(float*)(h_split + (size_t)N * (4 * D) + (size_t)r * 4) = pow2f(-sh);
+        }
+        if (r < N) {
+            float* __restrict__ o = h0 + (size_t)r * D + 4 * q;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) h0[(size_t)r * D + 16 * t + c16] = v[t];
-                if (SPLIT) {
-                    _Float16* __restrict__ sp = (_Float16*)(h_split + (size_t)r * (4 * D));
+            for (int t = 0; t < NT; ++t) *(f32x4*)(o + 16 * t) = v[t];
+            if (SPLIT) {
+                _Float16* __restrict__ sp = (_Float16*)(h_split + (size_t)r * (4 * D)) + 4 * q;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
+                for (int t = 0; t < NT; ++t) {
+                    ip_f16x4 hi4, lo4;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
                         _Float16 hi, lo;
-                        split2h(v[t] * up, hi, lo);
-                        sp[16 * t + c16] = hi;
-                        sp[D + 16 * t + c16] = lo;
+                        split2h(v[t][s] * up, hi, lo);
+                        hi4[s] = hi;
+                        lo4[s] = lo;
                     }
-                }
-            }
-            if (SPLIT) {                                  // range guard (common.h); all lanes take part in the reduction
-                float tiny = 0.f, nz = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { tiny += (float)range_tiny(v[t] * up); nz += v[t] != 0.f ? 1.f : 0.f; }
-                if (__ballot(tiny != 0.f)) {
-                    for (int i = 0; i < 2; ++i) {
-                        float& z = i ? nz : tiny;
-                        z += dpp_take<0xB1, 0xF>(z);
-                        z += dpp_take<0x4E, 0xF>(z);
-                        z += dpp_take<0x141, 0xF>(z);
-                        z += dpp_take<0x140, 0xF>(z);
-                    }
-                    if (r < N && c16 == 0) range_raise(range_flag, GHF_RANGE_ROWS, (int)tiny, (int)nz);
+                    *(ip_f16x4*)(sp + 16 * t) = hi4;
+                    *(ip_f16x4*)(sp + D + 16 * t) = lo4;
                 }
             }
         }
+        if (SPLIT) {                                      // range guard (common.h); all lanes take part in the reduction
+            float tiny = 0.f, nz = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { tiny += (float)range_tiny(v[t][s] * up); nz += v[t][s] != 0.f ? 1.f : 0.f; }
+            if (__ballot(tiny != 0.f)) {
+                tiny = across_q(tiny, false);
+                nz = across_q(nz, false);
+                if (r < N && q == 0) range_raise(range_flag, GHF_RANGE_ROWS, (int)tiny, (int)nz);
+            }
+        }
+    }
+  }
 }
 
 // Fallback: one wave per row, lanes stride output columns.
@@ -143,21 +171,33 @@ int launch_input_proj(const float* x, const float* W_in, const float* b_in, int6
     GHF_REQUIRE(N > 0 && F > 0 && d > 0, "input_proj: N, F, d must be positive");
     GHF_REQUIRE(!h_split || split_layout == GHF_WLAYOUT_SPLIT2H, "input_proj: h_split needs the SPLIT2H layout, got %d", split_layout);
     const bool fuse = h_split && split_layout == GHF_WLAYOUT_SPLIT2H;
-    const bool aligned = ((((uintptr_t)x | (uintptr_t)W_in) & 15) == 0);
+    const bool aligned = ((((uintptr_t)x | (uintptr_t)W_in | (uintptr_t)b_in | (uintptr_t)h0 | (uintptr_t)h_split) & 15) == 0);
     const bool mfma_ok = aligned && (F % 16) == 0 && (d % 16) == 0 && d <= 256;
     if (mfma_ok) {
         const int64_t rows_per_block = 4 * 16 * IP_MT;
-        const unsigned grid = (unsigned)cdiv(N, rows_per_block);
+        const int64_t nblk = cdiv(N, rows_per_block);
+        const size_t wlds = (size_t)d * (F + 4) * 4;                      // W_in in LDS when it leaves room for two workgroups per CU
+        const bool use_lds = wlds <= 72 * 1024 && nblk >= 64;
+        const unsigned grid = (unsigned)(use_lds ? (nblk < 1024 ? nblk : 1024) : nblk);
+        const size_t lds = use_lds ? wlds : 0;
         switch (d / 16) {
+#define GHF_IP_LAUNCH(NT, SP, WL, ...)                                                                                  \
+    do {                                                                                                                \
+        GHF_SET_MAX_LDS((input_proj_mfma_kernel<NT, SP, WL>), 72 * 1024);                                               \
+        input_proj_mfma_kernel<NT, SP, WL><<<grid, 256, lds, stream>>>(__VA_ARGS__);                                    \
+    } while (0)
 #define GHF_IP_CASE(NT)                                                                                                 \
     case NT:                                                                                                            \
-        if (fuse) input_proj_mfma_kernel<NT, true><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, (char*)h_split, range_flag_ptr());   \
-        else input_proj_mfma_kernel<NT, false><<<grid, 256, 0, stream>>>(x, W_in, b_in, N, F, h0, nullptr, nullptr);           \
+        if (fuse && use_lds) GHF_IP_LAUNCH(NT, true, true, x, W_in, b_in, N, F, h0, (char*)h_split, range_flag_ptr());   \
+        else if (fuse) GHF_IP_LAUNCH(NT, true, false, x, W_in, b_in, N, F, h0, (char*)h_split, range_flag_ptr());        \
+        else if (use_lds) GHF_IP_LAUNCH(NT, false, true, x, W_in, b_in, N, F, h0, nullptr, nullptr);                     \
+        else GHF_IP_LAUNCH(NT, false, false, x, W_in, b_in, N, F, h0, nullptr, nullptr);                                 \
         break;
             GHF_IP_CASE(1) GHF_IP_CASE(2) GHF_IP_CASE(3) GHF_IP_CASE(4) GHF_IP_CASE(5) GHF_IP_CASE(6)
             GHF_IP_CASE(7) GHF_IP_CASE(8) GHF_IP_CASE(9) GHF_IP_CASE(10) GHF_IP_CASE(11) GHF_IP_CASE(12)
             GHF_IP_CASE(13) GHF_IP_CASE(14) GHF_IP_CASE(15) GHF_IP_CASE(16)
 #undef GHF_IP_CASE
+#undef GHF_IP_LAUNCH
         }
     } else {
         input_proj_simple_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(x, W_in, b_in, N, F, d, h0);
