@@ -69,6 +69,13 @@ __device__ __forceinline__ void lds_ld_b32_x6(const unsigned (&a)[6], int (&v)[6
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]) : "memory");
 }
+__device__ __forceinline__ void lds_ld_b32_x10(const unsigned (&a)[10], int (&v)[10]) {
+    asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %11\n\tds_read_b32 %2, %12\n\tds_read_b32 %3, %13\n\tds_read_b32 %4, %14\n\t"
+                 "ds_read_b32 %5, %15\n\tds_read_b32 %6, %16\n\tds_read_b32 %7, %17\n\tds_read_b32 %8, %18\n\tds_read_b32 %9, %19\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]), "=&v"(v[9])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]) : "memory");
+}
 __device__ __forceinline__ void lds_ld_b64_x2(unsigned a0, unsigned a1, f32x2& v0, f32x2& v1) {
     asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
 }
@@ -95,7 +102,7 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #define GHF_BX_SB 2          // fold: 16-byte reads per step
 #endif
 #ifndef GHF_BX_RD
-#define GHF_BX_RD 3          // fold: steps in flight (<= 4)
+#define GHF_BX_RD 3          // fold: steps in flight (<= 6)
 #endif
 // Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results): 1 no B refills, 2 no A-tile DMA, 4 no MFMAs,
 // 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table), 128 one
@@ -111,6 +118,11 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #endif
 #ifndef GHF_BX_YT
 #define GHF_BX_YT 0
+#endif
+#ifndef GHF_BX_LATE
+#define GHF_BX_LATE 0         // 1: the destination-row tile of chunk k+1 may land after the barrier, behind a flag the consumers
+                              // wait for before phase 1 (GHF_VARIANT=bxLATE1).  Measured: no gain (3.51 vs 3.44 ms) — the wait only
+                              // moves to the helpers' next chunk, the tile's ~3,000-cycle landing is longer than what precedes the fold
 #endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
@@ -151,7 +163,7 @@ template <> struct BxCfg<128> {
     static constexpr int BN = 2 * U * UW;          // 4 helper waves x 64 lanes x U units x UW positions / 128
     static constexpr int MTC = (CR + 15) / 16;     // row tiles per chunk
     static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
-    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 32;
+    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 48;
 };
 // hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk decides:
 // long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block (two units per helper
@@ -161,7 +173,7 @@ template <> struct BxCfg<64> {
     static constexpr int BN = 4 * U * UW;          // 256 lanes x U units x UW positions / 64
     static constexpr int MTC = (CR + 15) / 16;
     static constexpr bool YT = false;
-    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 32;
+    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 48;
 };
 
 struct BxChunk { int r; int e0; int rows; };
@@ -211,7 +223,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr bool YT = C::YT;
     constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 4 * TILE, TAB_OFF = (YT ? 5 : 4) * TILE, META_OFF = TAB_OFF + BN * 4,
                        DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: 128 bytes of zeros
-                       FLAG_OFF = ZERO_OFF + 128;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read)
+                       FLAG_OFF = ZERO_OFF + 128;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read),
+                                                          // 4 helper words (chunks whose destination-row tile has landed)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;       // LDS byte address of smem (0 unless static LDS exists)
@@ -427,7 +440,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
             for (int i = 0; i < RBW; ++i) {
                 const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
-                if (RPP * rb >= rows) continue;             // (uniform) a piece without live rows is not issued
+                // (a piece without live rows is issued too when GHF_BX_LATE: every lane past the buffer — zeros, no memory
+                // access — so that the number of DMA instructions per tile is a constant the counted waits can name)
+                if (!GHF_BX_LATE && RPP * rb >= rows) continue;
                 const int g = (lane & (LPR - 1)) ^ akey(row);
                 // dead rows: an offset past the end of the buffer (zeros, no memory access)
                 const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : 0x7FFFFF00;
@@ -464,13 +479,28 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         auto fold_prep = [&](int j, int rows, int lane, int (&ri)[U]) {
             const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
             const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
+            // one batch of LDS reads for everything the preparation needs (three dependent round trips of ~250 cycles each
+            // when the run pass's two halves and the table were read one after the other): the destination of row r and of
+            // row r + 1 for both halves of the rows, and the first six table entries of this lane's units
+            constexpr int NP = (CR + 63) / 64;
+            static_assert(NP <= 2 && U <= 12, "run pass: two halves; table reads: two batches of six");
+            unsigned ba[10];
+            int bv[10];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int r = pass * 64 + lane;
+                const int rr = (pass < NP && r + 1 < rows) ? r : 0;
+                ba[2 * pass] = dd + 4 * rr;
+                ba[2 * pass + 1] = dd + 4 * (rr + 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ba[4 + k] = lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + (U * lane + (k < U ? k : 0)) / NU);
+            lds_ld_b32_x10(ba, bv);
             // 1. runs of equal destinations owned by this wave: add row r into row r + 1, ascending
 #pragma unroll
-            for (int pass = 0; pass < (CR + 63) / 64; ++pass) {
+            for (int pass = 0; pass < NP; ++pass) {
                 const int r = pass * 64 + lane;
-                const int rr = r + 1 < rows ? r : 0;
-                int a, b;
-                lds_ld_b32_x2(dd + 4 * rr, dd + 4 * (rr + 1), a, b);
+                const int a = bv[2 * pass], b = bv[2 * pass + 1];
                 const int nl = a - (int)node0 - hw * NPW;
                 unsigned long long mask = __ballot(r + 1 < rows && a == b && nl >= 0 && nl < NPW);
                 while (mask) {
@@ -486,9 +516,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 }
             }
             // 2. every owner lane: the staged row of its node, if any; then the table is free for the next chunk
-            static_assert(U <= 12, "table reads: two batches of six");
 #pragma unroll
-            for (int k0 = 0; k0 < U; k0 += 6) {
+            for (int k = 0; k < 6; ++k)
+                if (k < U) ri[k] = bv[4 + k];
+#pragma unroll
+            for (int k0 = 6; k0 < U; k0 += 6) {
                 unsigned ta[6];
                 int tv[6];
 #pragma unroll
@@ -532,7 +564,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1])::"memory");
                 else if (left == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(SB) : "memory");
                 else if (left == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(2 * SB) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(3 * SB) : "memory");
+                else if (left == 3) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(3 * SB) : "memory");
+                else if (left == 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(4 * SB) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(5 * SB) : "memory");   // (RD <= 6: lgkmcnt counts to 15)
 #pragma unroll
                 for (int i = 0; i < SB; ++i) {
                     const int g = st * SB + i, k = K0 + g / RPU, o = 4 * (g % RPU);
@@ -578,7 +612,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         Scales scP{1.f, 1.f}, scN{1.f, 1.f};               // scales of chunks k+2, k+3 (just requested)
         i32x2 d5{0, 0};                                    // chunk_tab entry of chunk k+5 (just requested)
         table_clear(lane);
-        if (hw == 0 && lane < 32 + 8) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);      // zeros and the eight flags behind them
+        if (hw == 0 && lane < 32 + 12) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);     // zeros and the twelve flags behind them
         int prev_rows = 1;
         if (nchunks > 0) {
             i32x2 dd[5];
@@ -605,7 +639,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             if (!(skip & 1)) dma_tile(P0_OFF, 0, 2, ch[0].rows, true, lane);
             if (!(skip & 2)) dma_tile(P1_OFF, 0, 3, ch[0].rows, false, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (GHF_BX_LATE && lane == 0) lds_st_b32(lds0 + FLAG_OFF + 32 + 4 * hw, 1);   // chunk 0's destination rows are in
         }
+        // DMA instructions per tile and helper wave (constant: dma_tile) — what the counted waits below leave in flight
+        constexpr int N_SRC = (skip & 1) ? 0 : RBW * NPL, N_DST = ((skip & 2) || YT) ? 0 : RBW * NPL;
+        constexpr int N_DESC = (GHF_BXEXP & 64) ? 1 : 5;   // descriptor loads per chunk: scales (2), words (2), chunk_tab entry (1)
         int ri[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) ri[k] = -1;
@@ -626,9 +664,18 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_STAMP(4);
             if (!(skip & 1)) dma_tile(P0_OFF + ((k + 1) & 1) * TILE, k + 1, 2, ch[1].rows, true, l0);
             if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l0);
+            if (GHF_BX_LATE && N_DST > 0) {
+                // chunk k's destination rows (requested at the end of chunk k-1) have landed once only the source-row DMAs
+                // just issued are in flight: tell the consumers, who need that tile for phase 1 only
+                if (k > 0) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SRC) : "memory");
+                    if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 32 + 4 * hw, k + 1);
+                }
+            }
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
                 fold_prep(k - 1, prev_rows, l0, ri);
+                BX_STAMP(5);                               // (stamps: the fold's preparation, apart from its reads and adds)
                 fold_units(k - 1, U0{}, U2{}, l0, ri);
             }
             BX_LGKM0();
@@ -652,7 +699,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_STAMP(1);
             if (!(GHF_BXEXP & 64)) table_write(k, ch[0].rows, l1);
             prev_rows = ch[0].rows;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both tiles of chunk k+1 have landed
+            // the source rows of chunk k+1 (requested at this chunk's start) must be in before the barrier; GHF_BX_LATE: the
+            // descriptor loads and the destination-row DMAs issued after them stay in flight across it
+            if (GHF_BX_LATE && N_DST > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DESC + N_DST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             BX_LGKM0();
             BX_STAMP(4);
         }
@@ -850,6 +900,15 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_STAMP(1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
+            if (GHF_BX_LATE && !(skip & 2) && !YT) {       // the destination-row tile of this chunk has landed (helpers' flags)
+                for (;;) {
+                    i32x4 f;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 32) : "memory");
+                    const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                    if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
             if (skip & 1) {                                // no source phase ran: the destination phase adds to the bias
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
