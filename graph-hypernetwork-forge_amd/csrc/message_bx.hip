@@ -120,9 +120,13 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #define GHF_BX_YT 0
 #endif
 #ifndef GHF_BX_LATE
-#define GHF_BX_LATE 0         // 1: the destination-row tile of chunk k+1 may land after the barrier, behind a flag the consumers
-                              // wait for before phase 1 (GHF_VARIANT=bxLATE1).  Measured: no gain (3.51 vs 3.44 ms) — the wait only
-                              // moves to the helpers' next chunk, the tile's ~3,000-cycle landing is longer than what precedes the fold
+#define GHF_BX_LATE 1         // 1: the destination-row tile of chunk k+1 may land after the barrier, behind a flag the consumers
+                              // wait for before phase 1 (the source-row tile still lands before it); with GHF_BX_DEFER the helpers are
+                              // the longer chain and this takes ~250 cycles per chunk off it (3.21 -> 3.13 ms at C3)
+#endif
+#ifndef GHF_BX_DEFER
+#define GHF_BX_DEFER 1        // 1: a chunk's rows are staged AFTER the next barrier (see the consumers' loop): no hand-shake among the
+                              // consumers, 3.25 -> 3.13 ms at C3 together with GHF_BX_LATE and the helpers' batched descriptor reads
 #endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
@@ -163,7 +167,7 @@ template <> struct BxCfg<128> {
     static constexpr int BN = 2 * U * UW;          // 4 helper waves x 64 lanes x U units x UW positions / 128
     static constexpr int MTC = (CR + 15) / 16;     // row tiles per chunk
     static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
-    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 48;
+    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 64;
 };
 // hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk decides:
 // long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block (two units per helper
@@ -173,7 +177,7 @@ template <> struct BxCfg<64> {
     static constexpr int BN = 4 * U * UW;          // 256 lanes x U units x UW positions / 64
     static constexpr int MTC = (CR + 15) / 16;
     static constexpr bool YT = false;
-    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 48;
+    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 64;
 };
 
 struct BxChunk { int r; int e0; int rows; };
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 4 * TILE, TAB_OFF = (YT ? 5 : 4) * TILE, META_OFF = TAB_OFF + BN * 4,
                        DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: 128 bytes of zeros
                        FLAG_OFF = ZERO_OFF + 128;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read),
-                                                          // 4 helper words (chunks whose destination-row tile has landed)
+                                                          // 4 helper words (chunks whose destination-row tile has landed), 4 consumer
+                                                          // words (the last chunk's hand-shake when staging is deferred)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;       // LDS byte address of smem (0 unless static LDS exists)
@@ -428,15 +433,20 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         };
         // ---- LDS-DMA gather of one A tile: piece = RPP consecutive rows of one plane (1 KiB), LPR lanes per row; the
         // granules of a row are XOR-swizzled by akey(row), as the consumers' fragment reads expect ----
-        auto dma_tile = [&](unsigned tile_off, int j, int which /*2: src ids, 3: dst ids*/, int rows, bool nt, int lane) {
-            const unsigned ids = lds0 + meta_off(j) + 4 * (which * CRP);
-            if (GHF_BXEXP & 2) return;
-            static_assert(RBW <= 6, "ids of a tile: one batched read");
+        // (the ids of a tile's rows are read apart from the issue: one LDS round trip — ~250 cycles here — that the loop below
+        // places behind other waits instead of in front of every tile's DMA instructions)
+        static_assert(RBW <= 6, "ids of a tile: one batched read");
+        auto id_addr = [&](int j, int which /*2: src ids, 3: dst ids*/, int i, int lane) -> unsigned {
+            return lds0 + meta_off(j) + 4 * (which * CRP) + 4 * (RPP * (hw + TW * (i < RBW ? i : 0)) + lane / LPR);
+        };
+        auto dma_ids = [&](int j, int which, int lane, int (&id)[6]) {
             unsigned ia[6];
-            int id[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ia[i] = ids + 4 * (RPP * (hw + TW * (i < RBW ? i : 0)) + lane / LPR);
+            for (int i = 0; i < 6; ++i) ia[i] = id_addr(j, which, i, lane);
             lds_ld_b32_x6(ia, id);
+        };
+        auto dma_issue = [&](unsigned tile_off, int rows, bool nt, int lane, const int (&id)[6]) {
+            if (GHF_BXEXP & 2) return;
 #pragma unroll
             for (int i = 0; i < RBW; ++i) {
                 const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
@@ -456,13 +466,19 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 }
             }
         };
+        auto dma_tile = [&](unsigned tile_off, int j, int which, int rows, bool nt, int lane) {
+            int id[6];
+            dma_ids(j, which, lane, id);
+            dma_issue(tile_off, rows, nt, lane, id);
+        };
         // ---- table: node -> the last row of its run in chunk j (rows sorted by destination) -----------------------
-        auto table_write = [&](int j, int rows, int lane) {
-            const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
+        auto table_addr = [&](int j, int rows, int lane, int next) -> unsigned {      // destination of my row (next: of the row behind it)
             const int row = hw * RPH + lane;
             const int rr = row < rows ? row : rows - 1;
-            int d0, d1;
-            lds_ld_b32_x2(dd + 4 * rr, dd + 4 * (rr + 1 < rows ? rr + 1 : rr), d0, d1);
+            return lds0 + meta_off(j) + 4 * (3 * CRP) + 4 * (next && rr + 1 < rows ? rr + 1 : rr);
+        };
+        auto table_store = [&](int rows, int lane, int d0, int d1) {
+            const int row = hw * RPH + lane;
             if (lane < RPH && row < rows && (row + 1 >= rows || d0 != d1)) lds_st_b32(lds0 + TAB_OFF + 4 * (unsigned)(d0 - (int)node0), row);
         };
         auto table_clear = [&](int lane) {
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         Scales scP{1.f, 1.f}, scN{1.f, 1.f};               // scales of chunks k+2, k+3 (just requested)
         i32x2 d5{0, 0};                                    // chunk_tab entry of chunk k+5 (just requested)
         table_clear(lane);
-        if (hw == 0 && lane < 32 + 12) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);     // zeros and the twelve flags behind them
+        if (hw == 0 && lane < 32 + 16) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);     // zeros and the sixteen flags behind them
         int prev_rows = 1;
         if (nchunks > 0) {
             i32x2 dd[5];
@@ -647,6 +663,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         int ri[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) ri[k] = -1;
+        int sid[6] = {0, 0, 0, 0, 0, 0};                   // source ids of the NEXT chunk's rows (read at the end of a chunk)
+        if (nchunks > 0 && !(skip & 1)) dma_ids(1, 2, lane, sid);
         for (int k = 0; k < nchunks; ++k) {
             __builtin_amdgcn_s_barrier();                  // ---- chunk k
             BX_STAMP(0);
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
-            if (!(skip & 1)) dma_tile(P0_OFF + ((k + 1) & 1) * TILE, k + 1, 2, ch[1].rows, true, l0);
+            if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, true, l0, sid);
             if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l0);
             if (GHF_BX_LATE && N_DST > 0) {
                 // chunk k's destination rows (requested at the end of chunk k-1) have landed once only the source-row DMAs
@@ -674,12 +692,31 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
+                if (GHF_BX_DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
                 fold_prep(k - 1, prev_rows, l0, ri);
                 BX_STAMP(5);                               // (stamps: the fold's preparation, apart from its reads and adds)
                 fold_units(k - 1, U0{}, U2{}, l0, ri);
             }
             BX_LGKM0();
             if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k + 1);   // this wave is through with Y(k-1) and the table
+            // what the rest of the chunk reads from the descriptors, in one round trip taken while the other helper waves catch
+            // up: the destination ids of chunk k+1's rows (its tile's DMA) and my row's destination in chunk k (the table)
+            int did[6], td[2];
+            {
+                const int lb = opaque_lane(lane);
+                unsigned ba[10];
+                int bv[10];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ba[i] = id_addr(k + 1, 3, i, lb);
+                ba[6] = table_addr(k, ch[0].rows, lb, 0);
+                ba[7] = table_addr(k, ch[0].rows, lb, 1);
+                ba[8] = ba[9] = ba[6];
+                lds_ld_b32_x10(ba, bv);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) did[i] = bv[i];
+                td[0] = bv[6];
+                td[1] = bv[7];
+            }
             BX_STAMP(2);
             // the table of chunk k is written by all helper waves for all of them: every wave must have read (and cleared)
             // its entries of chunk k-1 first; without a tile of their own the staged rows also sit where the next
@@ -695,10 +732,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 wdL = load_words(ch[4], l1);
             }
             d5 = load_desc(k + 5);
-            if (!YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l1);
+            if (!YT && !(skip & 2)) dma_issue(P1_OFF + ((k + 1) & 1) * TILE, ch[1].rows, false, l1, did);
             BX_STAMP(1);
-            if (!(GHF_BXEXP & 64)) table_write(k, ch[0].rows, l1);
+            if (!(GHF_BXEXP & 64)) table_store(ch[0].rows, l1, td[0], td[1]);
             prev_rows = ch[0].rows;
+            if (!(skip & 1)) dma_ids(k + 2, 2, l1, sid);     // (published at this chunk's start by every helper wave; all are past their flag)
             // the source rows of chunk k+1 (requested at this chunk's start) must be in before the barrier; GHF_BX_LATE: the
             // descriptor loads and the destination-row DMAs issued after them stay in flight across it
             if (GHF_BX_LATE && N_DST > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DESC + N_DST) : "memory");
@@ -881,6 +919,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
             for (int t = 0; t < NTW; ++t) bv[t] = *bx_at<float>(bias, (uint32_t)(r * D + (tw * NTW + t) * 16 + c16) * 4u);
         };
+        int mt_prev = 0;
+        static_assert(!(GHF_BX_DEFER && GHF_BX_YT), "GHF_BX_DEFER stages into the aliased tile");
         if (nchunks > 0) {
             ch = decode(load_desc(0));
             dn = load_desc(1);
@@ -894,6 +934,15 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             const int* meta = (const int*)(smem + meta_off(k));
             __syncthreads();                               // ---- chunk k
             BX_STAMP(0);
+            // GHF_BX_DEFER: the previous chunk's rows go to their staging tile (that chunk's destination-row tile) only now:
+            // behind the barrier every consumer wave is through with that tile, so there is no hand-shake among the consumers,
+            // and the accumulators are not needed before this chunk's first phase ends.  The helpers wait for the flag.
+            if (GHF_BX_DEFER && k > 0) {
+                if (!(GHF_BXEXP & 16)) write_rows(mt_prev, P1_OFF + ((k - 1) & 1) * TILE);
+                BX_LGKM0();
+                if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
+                BX_STAMP(3);
+            }
             const BxChunk nx = decode(dn);
             // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
             if (!(skip & 1)) stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v);
@@ -919,20 +968,28 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
             // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it
-            if (!YT && lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k + 1);
-            for (;;) {
-                i32x4 f;
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + (YT ? 0 : 16)) : "memory");
-                const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
-                if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
-                __builtin_amdgcn_s_sleep(1);
+            // the last chunk (and every chunk without GHF_BX_DEFER) stages its rows here, once all four consumer waves have read
+            // the tile they overwrite (flag words; YT: once every helper wave has folded the previous chunk's rows)
+            const bool stage_now = !GHF_BX_DEFER || k + 1 == nchunks;
+            if (stage_now) {
+                const unsigned fw = GHF_BX_DEFER ? FLAG_OFF + 48 : FLAG_OFF + (YT ? 0 : 16);      // (DEFER: words of their own)
+                const int fv = GHF_BX_DEFER ? 1 : k + 1;
+                if (!YT && lane == 0) lds_st_b32(lds0 + (GHF_BX_DEFER ? FLAG_OFF + 48 : FLAG_OFF + 16) + 4 * tw, fv);
+                for (;;) {
+                    i32x4 f;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + fw) : "memory");
+                    const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                    if (__builtin_amdgcn_readfirstlane(lo) >= fv) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!(GHF_BXEXP & 16)) write_rows(mt, YT ? Y_OFF : P1_OFF + (k & 1) * TILE);
             }
-            if (!(GHF_BXEXP & 16)) write_rows(mt, YT ? Y_OFF : P1_OFF + (k & 1) * TILE);
-            else
+            if (GHF_BXEXP & 16)
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) asm volatile("" ::"v"(acc[m][t]));
+            mt_prev = mt;
             ch = nx;
             wscale = wscale_n;
 #pragma unroll
