@@ -128,6 +128,12 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #define GHF_BX_DEFER 1        // 1: a chunk's rows are staged AFTER the next barrier (see the consumers' loop): no hand-shake among the
                               // consumers, 3.25 -> 3.13 ms at C3 together with GHF_BX_LATE and the helpers' batched descriptor reads
 #endif
+#ifndef GHF_BX_SCHED
+#define GHF_BX_SCHED 1        // 1: the weight refills of a k-step stay behind its MFMAs (scheduling barriers)
+#endif
+#ifndef GHF_BX_FLAGWAIT
+#define GHF_BX_FLAGWAIT 1      // 1: the staged rows are drained (lgkmcnt) before their flag is set (0 measured the same; kept conservative)
+#endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
 #endif
@@ -859,10 +865,14 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                         }
                     }
                 }
+#if GHF_BX_SCHED
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 BX_STAMP(5);
                 if (!(GHF_BXEXP & 1)) load_b_step(r_next, ph_next, j);
+#if GHF_BX_SCHED
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 BX_STAMP(7);
             }
 #pragma unroll
@@ -939,7 +949,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             // and the accumulators are not needed before this chunk's first phase ends.  The helpers wait for the flag.
             if (GHF_BX_DEFER && k > 0) {
                 if (!(GHF_BXEXP & 16)) write_rows(mt_prev, P1_OFF + ((k - 1) & 1) * TILE);
+#if GHF_BX_FLAGWAIT
                 BX_LGKM0();
+#endif
                 if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
                 BX_STAMP(3);
             }
