@@ -24,11 +24,14 @@
 // LDS: P0[2] (source-row tiles), P1[2] (destination-row tiles), CR * 4d bytes each; table [BN]; four chunk descriptors
 // ("meta": the rows' scales and node ids); a KiB for DMA pieces past a tile, 128 bytes of zeros, eight flag words.
 // ONE workgroup barrier per chunk.  During chunk k (between barriers k and k + 1):
-//   consumers: phase 0 (h_src x W_msg) from P0[k&1], phase 1 (h_dst x W_self) from P1[k&1]; once all four have read that
-//              tile (flag words), the chunk's rows Y(k) overwrite it
-//   helpers:   DMA P0[(k+1)&1] <- source rows of chunk k+1 (HBM: a whole chunk to land); fold Y(k-1) out of P1[(k-1)&1];
-//              once all four have folded (flag words), DMA that tile <- destination rows of chunk k+1 (L2); table of
-//              chunk k; the descriptor pipeline (chunk_tab entry k+5, edge words k+4, row scales k+3, publish k+2)
+//   consumers: stage Y(k-1) into P1[(k-1)&1] (behind the barrier every consumer is through with that tile; flag "staged");
+//              phase 0 (h_src x W_msg) from P0[k&1]; wait for the flag "destination rows of chunk k landed"; phase 1
+//              (h_dst x W_self) from P1[k&1]; the accumulators keep Y(k) until the next barrier
+//   helpers:   DMA P0[(k+1)&1] <- source rows of chunk k+1 (HBM: a whole chunk to land); counted vmcnt wait: the destination
+//              rows of chunk k, requested at the end of chunk k-1, are in (flag "landed"); wait for "staged", fold Y(k-1) out
+//              of P1[(k-1)&1]; once all four have folded (flag words), DMA that tile <- destination rows of chunk k+1 (L2; may
+//              land after the barrier); table of chunk k; the descriptor pipeline (chunk_tab entry k+5, edge words k+4, row
+//              scales k+3, publish k+2); counted vmcnt wait: the source rows of chunk k+1 are in
 // Template parameter SKIP: the instances for the backward's two gradient passes, whose weights have one zero half
 // (GHF_FLAG_ZERO_SRC / GHF_FLAG_ZERO_DST): that half's gathers and products are compiled out.
 #include "common.h"
