@@ -668,7 +668,6 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         }
         // DMA instructions per tile and helper wave (constant: dma_tile) — what the counted waits below leave in flight
         constexpr int N_SRC = (skip & 1) ? 0 : RBW * NPL, N_DST = ((skip & 2) || YT) ? 0 : RBW * NPL;
-        constexpr int N_DESC = (GHF_BXEXP & 64) ? 1 : 5;   // descriptor loads per chunk: scales (2), words (2), chunk_tab entry (1)
         int ri[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) ri[k] = -1;
@@ -747,8 +746,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             prev_rows = ch[0].rows;
             if (!(skip & 1)) dma_ids(k + 2, 2, l1, sid);     // (published at this chunk's start by every helper wave; all are past their flag)
             // the source rows of chunk k+1 (requested at this chunk's start) must be in before the barrier; GHF_BX_LATE: the
-            // descriptor loads and the destination-row DMAs issued after them stay in flight across it
-            if (GHF_BX_LATE && N_DST > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DESC + N_DST) : "memory");
+            // destination-row DMAs issued last stay in flight across it
+            // (counted in DMA instructions only — one per builtin; the descriptor loads before them are waited for as well:
+            // how many instructions the compiler makes of those is not this code's to assume)
+            if (GHF_BX_LATE && N_DST > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_DST) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             BX_LGKM0();
             BX_STAMP(4);
