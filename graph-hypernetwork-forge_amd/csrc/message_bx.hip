@@ -137,6 +137,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_FLAGWAIT
 #define GHF_BX_FLAGWAIT 1      // 1: the staged rows are drained (lgkmcnt) before their flag is set (0 measured the same; kept conservative)
 #endif
+#ifndef GHF_BX_FOLDMASK
+#define GHF_BX_FOLDMASK 0
+#endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
 #endif
@@ -560,6 +563,29 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         auto fold_units = [&](int j, auto k_lo, auto k_hi, int lane, const int (&ri)[U]) {
             constexpr int K0 = decltype(k_lo)::value, K1 = decltype(k_hi)::value;
             const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
+#if GHF_BX_FOLDMASK
+            // (experiment, off: same time — 3.26 vs 3.22-3.29 ms — so the fold is bound neither by LDS bandwidth nor by the zero
+            // reads) only the lanes whose node has a row read and add, unit by unit, each unit behind its own wait
+#pragma unroll
+            for (int k = K0; k < K1; ++k) {
+                const int part = (U * lane + k) % NU, r = ri[k];
+                if (r >= 0) {
+                    const unsigned a = Y + (unsigned)r * (D * 4) + (unsigned)(((part * UW) ^ (((r >> 2) & 1) << 5)) * 4);
+                    f32x4 y8[UW / 4];
+                    static_assert(UW == 32, "eight reads per unit");
+                    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                                 "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(y8[0]), "=&v"(y8[1]), "=&v"(y8[2]), "=&v"(y8[3]), "=&v"(y8[4]), "=&v"(y8[5]), "=&v"(y8[6]), "=&v"(y8[7])
+                                 : "v"(a) : "memory");
+#pragma unroll
+                    for (int i = 0; i < UW / 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sums[k][4 * i + e] += y8[i][e];
+                }
+            }
+            return;
+#endif
             // the unit's bytes in Y (a lane whose node has no row in this chunk reads — and adds — zeros: no branch)
             unsigned ua[U];
 #pragma unroll
