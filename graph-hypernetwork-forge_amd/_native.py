@@ -414,14 +414,15 @@ def rs_supported(d: int) -> bool:
     return bool(load().ghf_message_rs_supported(d)) and os.environ.get("GHF_KERNEL") != "generic"
 
 
-RS_MIN_RELATIONS = 128
+RS_MIN_RELATIONS = 160
 
 
 def prefer_rs(d: int, R: int) -> bool:
     """Whether an inference plan for hidden size d and R relations should be a CSR plan for the relation-stationary layer:
-    always where no destination-block kernel exists (d >= 256); at d = 128 from about 128 relations on — the block
-    kernel re-streams a relation's weights per (block, relation) chunk, so its time grows with R (C3-sized graph: 4.1 ms per
-    layer at R = 64, 11.3 ms at 256) while the relation-stationary layer's does not (6.0 ms)."""
+    always where no destination-block kernel exists (d >= 256); at d = 128 from about 160 relations on — the block
+    kernel re-streams a relation's weights per (block, relation) chunk, so its time grows with R while the
+    relation-stationary layer's does not (tools/relation_sweep_rs.py, C3-sized graph, ms per layer, message_bx / relation-
+    stationary: R = 64: 3.5 / 5.8, 96: 4.1 / 5.6, 128: 4.8 / 5.7, 192: 9.2 / 5.9, 256: 11.0 / 5.7)."""
     if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("bx", "hx", "pp"):
         return False
     return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
