@@ -39,6 +39,8 @@ for _k in ("U", "UW", "CR", "SB", "RD", "AD", "PK", "YT", "PRIO", "LATE", "DEFER
     _g = _re.search(r"bx%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX_%s=%s" % (_k, _g.group(1)))
+if "eoslow" in VARIANT:
+    FLAGS.append("-DGHF_EO_SLOW_FRAG")                  # debug: edge_outer_h fragments read element by element
 _m = _re.search(r"(?<!bx)exp(\d+)", VARIANT)
 if _m:
     # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags

@@ -70,7 +70,7 @@ SIGNATURES = {
     "ghf_segment_partial_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
-    "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "ghf_add3": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -564,12 +564,12 @@ def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.T
     h, G = _req(h, torch.float32, "h"), _req(G, torch.float32, "G")
     d, ns = h.size(1), slice_tab.size(0)
     D = min(d, 128)
-    ws = torch.empty(ns * (2 * D * D + D), dtype=torch.float32, device=h.device)
+    ws = torch.empty(ns * (2 * D * D + D) + 64, dtype=torch.float32, device=h.device)
     dW = torch.empty(R, 2 * d, d, dtype=torch.float32, device=h.device)
     db = torch.empty(R, d, dtype=torch.float32, device=h.device)
     _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), _ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")),
                               _ptr(_req(slice_tab, torch.int64, "slice_tab")), _ptr(_req(slice_off, torch.int64, "slice_off")),
-                              ns, R, d, _ptr(ws), _ptr(dW), _ptr(db), _stream()), "ghf_edge_outer")
+                              ns, R, d, h.size(0), _ptr(ws), _ptr(dW), _ptr(db), _stream()), "ghf_edge_outer")
     return dW, db
 
 

@@ -12,6 +12,9 @@
 // First version: exact fp32 (v_mfma_f32_16x16x4_f32 / vector ALU), deterministic summation orders, any d <= 1024.
 #include "common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace ghf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -337,10 +340,188 @@ static int edge_outer_launch(const float* h, const float* G, const int64_t* ia, 
     return GHF_OK;
 }
 
+// ---- the same gradients on the 16-bit matrix pipe (d % 128 == 0) ------------------------------------------------------
+// Both operands of dW = X^T G have the contraction index — the edge — as their ROW index in memory, and a
+// v_mfma_f32_16x16x32_f16 operand wants eight consecutive k per lane: a transpose.  gfx950's ds_read_b64_tr_b16 does it on
+// the way out of LDS (a 4-row x 16-column block of 16-bit elements per 16 lanes, delivered column-major), so the tiles
+// are stored row-major [edge][feature] as the gather delivers them — cut into two fp16 pieces with ONE power-of-two scale
+// per tensor (the largest magnitude of h resp. G lifted into [2^13, 2^14): a per-row scale cannot leave a sum over rows) —
+// and read back as fragments: hi*hi + hi*lo + lo*hi in fp32, 22 significand bits relative to the tensor's largest
+// entries (norm-wise the accuracy of the fp32 chain; entries far below the tensor's largest lose bits, which a sum over
+// thousands of edges does not see).  5.3x less matrix time than v_mfma_f32_16x16x4_f32.
+// LDS image of a [32 edges][128 features] fp16 tile, 256-byte rows: chunk (16 bytes) ch of row r at
+//   256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3)))        (conflict-free for the transposed reads; cdna guide, T10)
+typedef _Float16 eo_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 eo_f16x8 __attribute__((ext_vector_type(8)));
+typedef short eo_s16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_absmax(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));          // (non-negative floats order as their bits)
+}
+
+__device__ __forceinline__ unsigned eo_off(int row, int ch) { return 256u * row + 16u * (unsigned)(ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(512) void edge_outer_h_kernel(
+    const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+    const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
+    const int64_t* __restrict__ slice_tab, const unsigned* __restrict__ amax /* bits of max|h|, max|G| */,
+    float* __restrict__ partial, float* __restrict__ partial_b) {
+    constexpr int D = 128, RG = 4, CG = 2, NT = 512;
+    constexpr int F4 = D / 4;                             // float4 per row of h / G
+    constexpr int LPR = EO_ET * F4 / NT;                  // (row, float4) items each thread moves per region and tile: 2
+    constexpr int IMG = EO_ET * 256;                      // bytes of one [32][128] fp16 image
+    // per buffer: X_src hi, lo; X_dst hi, lo; G hi, lo
+    extern __shared__ __attribute__((aligned(16))) char eoh_lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int rg = w / CG, cg = w % CG;                   // rows rg*64 .. +63 of [X_src | X_dst], columns cg*64 .. +63 of G
+    const int c16 = lane & 15, Q = lane >> 4;
+    const int64_t e0 = slice_tab[3 * (size_t)blockIdx.x + 1], e1 = slice_tab[3 * (size_t)blockIdx.x + 2];
+    const int ntiles = (int)((e1 - e0 + EO_ET - 1) / EO_ET);
+    const int sx = split2h_shift(__uint_as_float(amax[0])), sg = split2h_shift(__uint_as_float(amax[1]));
+    const float upx = pow2f(sx), upg = pow2f(sg);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum[LPR];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < LPR; ++j) bsum[j] = zero4;
+
+    int64_t is[LPR], iv[LPR], id[LPR];                    // indices of the tile to gather next
+    f32x4 st[3][LPR];                                     // its rows on their way to LDS
+    auto load_idx = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int64_t e = e0 + (int64_t)tile * EO_ET + (t + NT * j) / F4;
+            const bool ok = e < e1;
+            is[j] = ok ? ia[e] : -1;
+            iv[j] = ok ? ib[e] : -1;
+            id[j] = ok ? dst[e] : -1;
+        }
+    };
+    auto gather = [&]() {
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int c4 = (t + NT * j) % F4;
+            const bool ok = is[j] >= 0;
+            st[0][j] = ok ? *(const f32x4*)(h + (size_t)is[j] * ld + xa_col + 4 * c4) : zero4;
+            st[1][j] = ok ? *(const f32x4*)(h + (size_t)iv[j] * ld + xb_col + 4 * c4) : zero4;
+            st[2][j] = ok ? *(const f32x4*)(G + (size_t)id[j] * ld + g_col + 4 * c4) : zero4;
+        }
+    };
+    auto commit = [&](int buf) {                          // cut into pieces, row-major images
+        char* base = eoh_lds + (size_t)buf * 6 * IMG;
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) {
+            const int row = (t + NT * j) / F4, c4 = (t + NT * j) % F4;
+            const unsigned o = eo_off(row, c4 >> 1) + 8u * (c4 & 1);
+#pragma unroll
+            for (int reg = 0; reg < 3; ++reg) {
+                const float up = reg == 2 ? upg : upx;
+                eo_f16x4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 hi, lo;
+                    split2h(st[reg][j][e] * up, hi, lo);
+                    hi4[e] = hi;
+                    lo4[e] = lo;
+                }
+                *(eo_f16x4*)(base + (2 * reg) * IMG + o) = hi4;
+                *(eo_f16x4*)(base + (2 * reg + 1) * IMG + o) = lo4;
+            }
+            bsum[j] += st[2][j];                          // db rides along: this thread's column quad, exact fp32
+        }
+    };
+    // fragment of 16 columns (features fb .. fb+15) x 32 rows (edges) of an image: what lane (Q, c16) needs is column c16, rows
+    // 8Q .. 8Q+7 — two transposed reads (rows 8Q.. and 8Q+4..); lane 4q+p of a 16-lane group supplies row r0+q, columns 4p..
+    const int gq = c16 >> 2, gp = c16 & 3;
+    auto frag = [&](const char* img, int fb) -> eo_f16x8 {
+#ifdef GHF_EO_SLOW_FRAG
+        {   // (debug) the same fragment, element by element
+            eo_f16x8 r;
+            const int col = fb + c16;
+            for (int e = 0; e < 8; ++e) r[e] = *(const _Float16*)(img + eo_off(8 * Q + e, col >> 3) + 2 * (col & 7));
+            return r;
+        }
+#endif
+        const int ch = (fb >> 3) + (gp >> 1);
+        typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+        const auto p0 = (__attribute__((address_space(3))) h4_t*)(img + eo_off(8 * Q + gq, ch) + 8u * (gp & 1));
+        const auto p1 = (__attribute__((address_space(3))) h4_t*)(img + eo_off(8 * Q + 4 + gq, ch) + 8u * (gp & 1));
+        const eo_f16x4 a = __builtin_bit_cast(eo_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(p0));
+        const eo_f16x4 b = __builtin_bit_cast(eo_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(p1));
+        // (whole-vector casts and one shuffle: hipcc turned an element-by-element copy of the two halves into permutes of
+        // their first dwords only)
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    load_idx(0);
+    gather();
+    load_idx(1);                                          // (past the slice: every lane reads nothing)
+    commit(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        gather();                                         // tile + 1 (indices were loaded an iteration ago)
+        load_idx(tile + 2);
+        const char* base = eoh_lds + (size_t)buf * 6 * IMG;
+        const char* ximg = base + (rg >> 1) * 2 * IMG;    // rows 0..127 of [X_src | X_dst] are the source image, 128..255 the destination one
+        const char* gimg = base + 4 * IMG;
+        eo_f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+            bh[bi] = frag(gimg, cg * 64 + 16 * bi);
+            bl[bi] = frag(gimg + IMG, cg * 64 + 16 * bi);
+        }
+#pragma unroll
+        for (int ai = 0; ai < 4; ++ai) {
+            const int fb = (rg & 1) * 64 + 16 * ai;
+            const eo_f16x8 ah = frag(ximg, fb), al = frag(ximg + IMG, fb);
+#pragma unroll
+            for (int bi = 0; bi < 4; ++bi) {
+                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[bi], acc[ai][bi], 0, 0, 0);
+                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[bi], acc[ai][bi], 0, 0, 0);
+                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[bi], acc[ai][bi], 0, 0, 0);
+            }
+        }
+        commit(buf ^ 1);
+        __syncthreads();
+    }
+    // partial product: tile (ai, bi) register s is row rg*64 + 16 ai + 4Q + s, column cg*64 + 16 bi + c16
+    const float down = pow2f(-sx) * pow2f(-sg);
+    float* P = partial + (size_t)blockIdx.x * 2 * D * D;
+#pragma unroll
+    for (int ai = 0; ai < 4; ++ai)
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                P[(size_t)(rg * 64 + 16 * ai + 4 * Q + s) * D + cg * 64 + 16 * bi + c16] = acc[ai][bi][s] * down;
+    // db: threads (row, c4) with equal c4 hold partial column sums; rows in thread order: fixed summation order
+    float* red = (float*)eoh_lds;                         // [NT / F4 = 16 row groups][D] (every tile read is behind the loop's last barrier)
+    f32x4 bs = zero4;
+#pragma unroll
+    for (int j = 0; j < LPR; ++j) bs += bsum[j];
+    *(f32x4*)(red + (size_t)(t / F4) * D + 4 * (t % F4)) = bs;
+    __syncthreads();
+    if (t < D) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / F4; ++k) s_ += red[k * D + t];
+        partial_b[(size_t)blockIdx.x * D + t] = s_;
+    }
+}
+
 int edge_outer_supported(int d) { return d == 64 || (d >= 128 && d <= BW_MAX_D && (d % 128) == 0); }
 
 int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
-                      const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
+                      const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db,
                       hipStream_t stream) {
     GHF_REQUIRE(edge_outer_supported(d), "edge_outer: d = %d has no tile (64 and multiples of 128 do; use ghf_group_outer)", d);
     GHF_REQUIRE(nslices > 0 && R > 0, "edge_outer: nothing to do");
@@ -348,12 +529,32 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
     float* partial = workspace;
     float* partial_b = workspace + (size_t)nslices * 2 * D * D;
     const unsigned gx = (unsigned)cdiv((int64_t)2 * D * D / 4 + D, 256);
+    // d % 128 == 0: two fp16 pieces on the 16-bit matrix pipe (edge_outer_h_kernel); GHF_EDGE_OUTER=exact keeps the fp32 MFMAs
+    static const bool exact = getenv("GHF_EDGE_OUTER") && !strcmp(getenv("GHF_EDGE_OUTER"), "exact");
+    unsigned* amax = (unsigned*)(partial_b + (size_t)nslices * D);     // two words behind the partial sums: max |h|, max |G|
+    const bool pieces = D == 128 && !exact;
+    if (pieces) {
+        GHF_REQUIRE(N > 0, "edge_outer: N (rows of h and G) must be given");
+        GHF_HIP_CHECK(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), stream));
+        const unsigned ag = (unsigned)(cdiv(N * d, 256 * 16) < 2048 ? cdiv(N * d, 256 * 16) : 2048);
+        absmax_kernel<<<ag, 256, 0, stream>>>(h, N * d, amax);
+        absmax_kernel<<<ag, 256, 0, stream>>>(G, N * d, amax + 1);
+        GHF_LAUNCH_CHECK();
+    }
     for (int rb = 0; rb < d / D; ++rb)                     // tile rows 2D*rb ..: two D-column pieces of [h_src | h_dst]
         for (int cb = 0; cb < d / D; ++cb) {
             const int fa = 2 * rb * D, fb = fa + D;        // first stacked feature of the two pieces
             const int64_t* ia = fa < d ? src : dst;
             const int64_t* ib = fb < d ? src : dst;
-            int rc = D == 128 ? edge_outer_launch<128>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
+            int rc = GHF_OK;
+            if (pieces) {
+                constexpr size_t lds = (size_t)2 * 6 * EO_ET * 256;
+                GHF_SET_MAX_LDS(edge_outer_h_kernel, lds);
+                edge_outer_h_kernel<<<(unsigned)nslices, 512, lds, stream>>>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, amax,
+                                                                            partial, partial_b);
+                GHF_LAUNCH_CHECK();
+            } else
+                rc = D == 128 ? edge_outer_launch<128>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
                                                        partial_b, stream)
                               : edge_outer_launch<64>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
                                                       partial_b, stream);

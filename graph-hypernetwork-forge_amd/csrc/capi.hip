@@ -267,10 +267,10 @@ int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* deg_
 int ghf_edge_outer_supported(int d) { return edge_outer_supported(d); }
 
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
-                   const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
+                   const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db,
                    void* stream) {
     GHF_REQUIRE(h && G && src && dst && slice_tab && slice_off && workspace && dW && db, "edge_outer: null pointer argument");
-    return launch_edge_outer(h, G, src, dst, slice_tab, slice_off, nslices, R, d, workspace, dW, db, (hipStream_t)stream);
+    return launch_edge_outer(h, G, src, dst, slice_tab, slice_off, nslices, R, d, N, workspace, dW, db, (hipStream_t)stream);
 }
 
 int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream) {

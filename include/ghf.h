@@ -266,11 +266,15 @@ int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, c
  *   db[r] = sum_{e in r} G[dst[e]]                             ([R][d])
  * src / dst [E]: the edges grouped by relation (ghf_group_edges); slice_tab [nslices][3] = (relation, first edge, end edge)
  * cuts every relation's range into slices, relations ascending, never across a relation; slice_off [R+1] = first slice of
- * each relation.  workspace: nslices * (2*D*D + D) floats, D = min(d, 128).  Exact fp32, fixed summation order. */
+ * each relation.  workspace: nslices * (2*D*D + D) + 64 floats, D = min(d, 128).  Fixed summation order.  d = 64: exact fp32
+ * (v_mfma_f32_16x16x4_f32); d % 128 == 0: two fp16 pieces per operand with ONE power-of-two scale per tensor (the largest
+ * magnitude of h resp. G — found by the call — lifted into [2^13, 2^14)), three v_mfma_f32_16x16x32_f16 per product, fp32
+ * accumulation: 22 significand bits relative to each tensor's largest entries (GHF_EDGE_OUTER=exact in the environment keeps
+ * the fp32 chain). */
 int ghf_edge_outer_supported(int d);
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
-                   const int64_t* slice_off, int64_t nslices, int R, int d, float* workspace, float* dW, float* db,
-                   void* stream);
+                   const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N /* rows of h and G */, float* workspace,
+                   float* dW, float* db, void* stream);
 /* Elementwise pieces of the backward: out = X * exp(log_scale[0]) (log_scale on the device: the generator's learnable
  * scale, reference weight_generator.py:137-141); out = a + b (+ c when non-NULL); out[i][:] = g[i] * X[i][:] (the two
  * gradients of score_triple, reference hypergnn.py:304-318).  out may alias an input. */
