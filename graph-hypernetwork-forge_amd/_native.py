@@ -25,6 +25,7 @@ GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 GHF_FLAG_ZERO_SRC = 4
 GHF_FLAG_ZERO_DST = 8
+GHF_FLAG_ADD_H = 16
 SRC_MASK = (1 << 28) - 1        # sorted_src of block plans: node id below bit 28, run head above
 WLAYOUT_NATURAL = 0
 WLAYOUT_FRAG16 = 1

@@ -95,7 +95,7 @@ def _layer_weights(plan: GraphPlan, Wm: Optional[torch.Tensor], Ws: Optional[tor
     return _native.weights_pack(Wm, Ws, transpose, R, d, plan.wlayout), None
 
 
-def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, flags: int, x_split=None) -> torch.Tensor:
+def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, flags: int, x_split=None, residual=None) -> torch.Tensor:
     """A message pass without tail (NO_TAIL / RAW_SUM) on the plan's kernel: the destination-block or generic kernel, or —
     CSR plans of wide rows — the relation-stationary layer."""
     out = torch.empty_like(x)
@@ -106,12 +106,16 @@ def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, fl
         _native.edge_transform_fwd(x, plan.rs, W, W_self, bias, Y)
         _native.segment_tail_fwd(Y, plan.rs, None, None, None, 0.0, out, flags=flags)
         return out
+    if residual is not None:                 # out = (the pass) + residual, added in the kernel's tail (GHF_FLAG_ADD_H): x_split names
+        _native.message_layer_fwd(residual, plan, W, W_self, bias, plan.wlayout, None, None, 0.0, out,      # the gathered rows
+                                  flags=flags | _native.GHF_FLAG_ADD_H, h_split=x_split)
+        return out
     _native.message_layer_fwd(x, plan, W, W_self, bias, plan.wlayout, None, None, 0.0, out, flags=flags, h_split=x_split)
     return out
 
 
-def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor, zero_half: int, x_split=None) -> torch.Tensor:
-    return _message(x, plan, W, W_self, zero_bias, _native.GHF_FLAG_RAW_SUM | zero_half, x_split)
+def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor, zero_half: int, x_split=None, residual=None) -> torch.Tensor:
+    return _message(x, plan, W, W_self, zero_bias, _native.GHF_FLAG_RAW_SUM | zero_half, x_split, residual)
 
 
 class _SplitCarry:
@@ -185,8 +189,13 @@ class MessageLayerFn(torch.autograd.Function):
             Gs = None                                                                   # both passes gather the same rows of G
             if plan.wlayout in _native.SPLIT_LAYOUTS and tp.rev.wlayout == plan.wlayout and plan.block_nodes > 1:
                 Gs = _native.split_rows(G, plan.wlayout)
-            dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs),
-                              _raw_message(G, tp.rev, Wr, Wr2, zero_b, _native.GHF_FLAG_ZERO_DST, Gs), out=dpre)
+            if Gs is not None and _native.side_output_supported(plan, h.size(1)) and _native.side_output_supported(tp.rev, h.size(1)):
+                # the three terms are added in the two passes' tails: dpre + self term, then + message term
+                t1 = _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs, residual=dpre)
+                dh = _raw_message(G, tp.rev, Wr, Wr2, zero_b, _native.GHF_FLAG_ZERO_DST, Gs, residual=t1)
+            else:
+                dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs),
+                                  _raw_message(G, tp.rev, Wr, Wr2, zero_b, _native.GHF_FLAG_ZERO_DST, Gs), out=dpre)
         return dh, dWm, dWs, db, dgamma, dbeta, None, None, None
 
 

@@ -332,7 +332,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 inv[gb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
                 const float* __restrict__ hp = h + (size_t)node * D + c0;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) x[gb][i] = no_tail ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4 * i);
+                for (int i = 0; i < NV; ++i)              // (GHF_FLAG_ADD_H: the residual operand also without the tail)
+                    x[gb][i] = (no_tail && !(no_tail & GHF_FLAG_ADD_H)) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4 * i);
             }
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const float av = a[c >> 2][c & 3] * inv[gb];
-                    y[c] = no_tail ? av : fmaxf(av + x[gb][c >> 2][c & 3], 0.f);
+                    y[c] = no_tail ? av + x[gb][c >> 2][c & 3] : fmaxf(av + x[gb][c >> 2][c & 3], 0.f);      // (x = 0 without ADD_H)
                     s += y[c];
                 }
                 if (!no_tail) {
@@ -1076,7 +1077,7 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
         message_bx_kernel<D, S><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
                                                                           a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
                                                                           a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
-                                                                          a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr(), a.agg_out);
+                                                                          a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);
         return GHF_OK;
     };
     if (skip == 1) go(std::integral_constant<int, 1>{});

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
                 for (; j < nslots; ++j) t0 += p[(size_t)j * sstr];
                 float t = ((t0 + t1) + (t2 + t3)) * inv;
                 if (agg_out) agg_out[(size_t)node * d + o] = t;
-                x[c] = no_tail ? t : fmaxf(t + h[(size_t)node * d + o], 0.f);
+                x[c] = no_tail ? ((no_tail & GHF_FLAG_ADD_H) ? t + h[(size_t)node * d + o] : t) : fmaxf(t + h[(size_t)node * d + o], 0.f);
                 s += x[c];
             }
         }
@@ -227,7 +227,7 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const dim3 grid((unsigned)cdiv(a.rows, a.block_nodes), (unsigned)cdiv(a.block_nodes, COMB_ROWS));
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
                                                    a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, a.h_split_out, a.wlayout,
-                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM), range_flag_ptr(), a.agg_out);
+                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }

@@ -43,6 +43,9 @@ extern "C" {
                                  may skip the source-row gathers and their products (the two gradient passes of the backward
                                  each have one zero half); the result is the same with or without the flag */
 #define GHF_FLAG_ZERO_DST 8   /* the same for the destination half (W_self); not both */
+#define GHF_FLAG_ADD_H   16   /* with NO_TAIL / RAW_SUM: h_out = (that result) + h — `h` then only names the rows to add (the gathers use
+                                 h_split): the backward accumulates its gradient terms this way.  Kernels with the side
+                                 output (ghf_message_side_output_supported) only */
 
 /* Weight layouts produced by ghf_weightgen_fwd and consumed by ghf_message_layer_fwd */
 #define GHF_WLAYOUT_NATURAL 0 /* W_msg[R][d_in][d_out], W_self[R][d_in][d_out] row-major, as the reference returns them */

@@ -473,6 +473,18 @@ def test_side_output_and_zero_half_flags(N, E, R, kind):
     with pytest.raises(ValueError, match="nothing to compute"):
         _native.message_layer_fwd(h_d, plan, W, None, zb, plan.wlayout, None, None, 0.0, out, h_split=hs,
                                   flags=_native.GHF_FLAG_RAW_SUM | _native.GHF_FLAG_ZERO_SRC | _native.GHF_FLAG_ZERO_DST)
+    # GHF_FLAG_ADD_H: the pass plus other rows, one fp32 add in the tail (how the backward sums its three terms)
+    other = torch.randn(N, d, device=DEV, generator=torch.Generator(DEV).manual_seed(9))
+    for flag in (_native.GHF_FLAG_NO_TAIL, _native.GHF_FLAG_RAW_SUM):
+        base, added = torch.empty_like(h_d), torch.full_like(h_d, float("nan"))
+        _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, None, None, 0.0, base, h_split=hs, flags=flag)
+        _native.message_layer_fwd(other, plan, W, None, t(b), plan.wlayout, None, None, 0.0, added, h_split=hs, flags=flag | _native.GHF_FLAG_ADD_H)
+        if flag == _native.GHF_FLAG_RAW_SUM:                    # no division: exactly one add
+            assert torch.equal(added, base + other)
+        else:                                                   # sum / indeg + h contracts into one fma: within an ulp of the two-step form
+            torch.testing.assert_close(added, base + other, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="ADD_H"):
+        _native.message_layer_fwd(other, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, out, h_split=hs, flags=_native.GHF_FLAG_ADD_H)
 
 
 @pytest.mark.parametrize("d,N,E,R,kind", [(20, 300, 2500, 5, "powerlaw"), (128, 1200, 9000, 6, "uniform"),
