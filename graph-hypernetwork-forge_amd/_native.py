@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 GHF_FLAG_ZERO_SRC = 4
@@ -57,7 +57,8 @@ SIGNATURES = {
     "ghf_weights_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "ghf_group_workspace_bytes": (_sz, [_i64]),
     "ghf_group_edges": (_i32, [_vp, _i64, _i32, _vp, _sz, _vp, _vp, _vp]),
-    "ghf_tail_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ghf_tail_bwd_workspace_floats": (_sz, [_i64, _i32]),
+    "ghf_tail_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_colsum_workspace_floats": (_sz, [_i64, _i32]),
     "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ghf_relu_mask": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -509,15 +510,21 @@ def group_edges(rel_id: torch.Tensor, R: int):
 
 
 def tail_bwd(grad_out: torch.Tensor, agg: torch.Tensor, h: torch.Tensor, gamma: torch.Tensor, eps: float, indeg: torch.Tensor,
-             drop: Optional[torch.Tensor] = None):
-    """(dpre, G, T) of include/ghf.h: ghf_tail_bwd (drop: the forward's scaled dropout mask, if any)."""
+             drop: Optional[torch.Tensor] = None, split_layout: Optional[int] = None):
+    """(dpre, G, G_split, dgamma, dbeta) of include/ghf.h: ghf_tail_bwd (drop: the forward's scaled dropout mask, if any;
+    split_layout: also return G cut as ``split_rows(G, split_layout)`` would, else G_split is None)."""
+    lib = load()
     g = _req(grad_out, torch.float32, "grad_out")
     N, d = h.shape
-    dpre, G, T = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-    _check(load().ghf_tail_bwd(_ptr(g), _ptr(_req(agg, torch.float32, "agg")), _ptr(_req(h, torch.float32, "h")),
-                               _ptr(_req(gamma, torch.float32, "gamma")), float(eps), _ptr(indeg), N, d, _ptr(dpre), _ptr(G),
-                               _ptr(T), _ptr(None if drop is None else _req(drop, torch.float32, "drop")), _stream()), "ghf_tail_bwd")
-    return dpre, G, T
+    dpre, G = torch.empty_like(h), torch.empty_like(h)
+    Gs = None if split_layout is None else alloc_split(N, d, split_layout, h.device)
+    dgb = torch.empty(2, d, dtype=torch.float32, device=h.device)
+    ws = torch.empty(max(int(lib.ghf_tail_bwd_workspace_floats(N, d)), 1), dtype=torch.float32, device=h.device)
+    _check(lib.ghf_tail_bwd(_ptr(g), _ptr(_req(agg, torch.float32, "agg")), _ptr(_req(h, torch.float32, "h")),
+                            _ptr(_req(gamma, torch.float32, "gamma")), float(eps), _ptr(indeg), N, d, _ptr(dpre), _ptr(G),
+                            _ptr(Gs), _ptr(dgb), _ptr(ws), _ptr(None if drop is None else _req(drop, torch.float32, "drop")),
+                            _stream()), "ghf_tail_bwd")
+    return dpre, G, Gs, dgb[0], dgb[1]
 
 
 def colsum(X: torch.Tensor, mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -8,8 +8,7 @@ The reference trains through plain autograd (``demo.py:79-101``, ``tests/test_hy
 
 and ``g' = dL/dh'``:
 
-    (dpre, G, T) = ghf_tail_bwd(g', out, h)          G_v = dpre_v / c_v
-    dgamma = colsum(T), dbeta = colsum(g')
+    (dpre, G, G_split, dgamma, dbeta) = ghf_tail_bwd(g', out, h)          G_v = dpre_v / c_v
     dWm[r] = sum_{e in r} h_u^T G_v      dWs[r] = sum_{e in r} h_v^T G_v      db[r] = sum_{e in r} G_v      (ghf_group_outer)
     dh = dpre + [sum_{e->v} G_v Ws[r]^T]_v + [sum_{e: src=u} G_{dst(e)} Wm[r]^T]_u
          (two ghf_message_layer_fwd passes with GHF_FLAG_RAW_SUM: transposed weights on the plan / on the reversed plan)
@@ -170,9 +169,11 @@ class MessageLayerFn(torch.autograd.Function):
         tp: TrainPlan = ctx.tp
         plan = tp.fwd
         g = grad_out.contiguous().float()
-        dpre, G, T = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg, drop=ctx.drop)
-        dgamma = _native.colsum(T)
-        dbeta = _native.colsum(g)
+        # both gradient passes gather the same rows of G: two-piece plans get them cut by the same launch
+        split_G = (ctx.needs_input_grad[0] and plan.wlayout in _native.SPLIT_LAYOUTS and tp.rev.wlayout == plan.wlayout
+                   and plan.block_nodes > 1)
+        dpre, G, Gs, dgamma, dbeta = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg, drop=ctx.drop,
+                                                      split_layout=plan.wlayout if split_G else None)
         if tp.slice_tab is not None:
             dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
             d = h.size(1)
@@ -186,9 +187,6 @@ class MessageLayerFn(torch.autograd.Function):
             zero_b = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)
             Wf, Wf2 = _layer_weights(plan, None, W_self.detach(), transpose=True)       # self term: rows keyed by destination
             Wr, Wr2 = _layer_weights(tp.rev, W_msg.detach(), None, transpose=True)      # message term: scattered to the sources
-            Gs = None                                                                   # both passes gather the same rows of G
-            if plan.wlayout in _native.SPLIT_LAYOUTS and tp.rev.wlayout == plan.wlayout and plan.block_nodes > 1:
-                Gs = _native.split_rows(G, plan.wlayout)
             if Gs is not None and _native.side_output_supported(plan, h.size(1)) and _native.side_output_supported(tp.rev, h.size(1)):
                 # the three terms are added in the two passes' tails: dpre + self term, then + message term
                 t1 = _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs, residual=dpre)

@@ -22,62 +22,242 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BW_MAX_D = 1024;
 constexpr int BW_PER_LANE = BW_MAX_D / 64;
 
-// one wave per row
+// ---- tail_bwd -----------------------------------------------------------------------------------------------------------
+// A fixed grid of workgroups walks the rows (wave w of workgroup b: row groups (4 b + w) + k * 4 * gridDim.x), so that the two
+// column sums dgamma = sum_v g'_v * xhat_v and dbeta = sum_v g'_v are accumulated in registers on the way — every wave over
+// its rows in order, the four waves of a workgroup in order through LDS, the workgroups' partial rows [gridDim.x][2][d] by
+// ghf_colsum's tree — instead of writing g' * xhat out and reading it and g' again.  G can leave in the two-fp16-piece
+// form as well (the gradient passes gather it that way): the same values ghf_split_rows would cut from the fp32 G.
+constexpr int TB_MAX_BLOCKS = 2048;
+typedef _Float16 tb_f16x4 __attribute__((ext_vector_type(4)));
+
+// sum / max over the groups of LPR consecutive lanes (LPR a power of two); every lane of a group gets the same bits
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LPR >= 2) v += dpp_take<0xB1, 0xF>(v);
+    if constexpr (LPR >= 4) v += dpp_take<0x4E, 0xF>(v);
+    if constexpr (LPR >= 8) v += dpp_take<0x141, 0xF>(v);
+    if constexpr (LPR >= 16) v += dpp_take<0x140, 0xF>(v);
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16);
+    if constexpr (LPR >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ float group_absmax(float v) {
+    if constexpr (LPR >= 2) v = fmaxf(v, dpp_take<0xB1, 0xF>(v));
+    if constexpr (LPR >= 4) v = fmaxf(v, dpp_take<0x4E, 0xF>(v));
+    if constexpr (LPR >= 8) v = fmaxf(v, dpp_take<0x141, 0xF>(v));
+    if constexpr (LPR >= 16) v = fmaxf(v, dpp_take<0x140, 0xF>(v));
+    if constexpr (LPR >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+    if constexpr (LPR >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// d = 4 * LPR * NV: a row is NV float4 per lane of a group of LPR lanes, a wave visits 64 / LPR consecutive rows at a time
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void tail_bwd_v4_kernel(const float* __restrict__ g_out, const float* __restrict__ agg,
+                                                          const float* __restrict__ h, const float* __restrict__ gamma, float eps,
+                                                          const int32_t* __restrict__ indeg, int64_t N,
+                                                          float* __restrict__ dpre, float* __restrict__ G, char* __restrict__ Gs,
+                                                          float* __restrict__ part, const float* __restrict__ drop,
+                                                          int32_t* __restrict__ range_flag) {
+    constexpr int D = 4 * LPR * NV, RPW = 64 / LPR;
+    __shared__ float red[4][2][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gam[j] = *(const f32x4*)(gamma + 4 * (j * LPR + cl));
+        dg[j] = db[j] = zero4;
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * RPW; base < N; base += stride) {
+        const bool ok = base + sub < N;
+        const int64_t v = ok ? base + sub : N - 1;                 // (a short last visit: the spare groups redo the last row, unstored)
+        const size_t row = (size_t)v * D;
+        f32x4 pre[NV], x[NV], dm[NV], go[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const size_t o = row + 4 * (j * LPR + cl);
+            pre[j] = *(const f32x4*)(agg + o) + *(const f32x4*)(h + o);
+            go[j] = *(const f32x4*)(g_out + o);
+            dm[j] = drop ? *(const f32x4*)(drop + o) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[j][k] = fmaxf(pre[j][k], 0.f) * dm[j][k];
+                s += x[j][k];
+            }
+        }
+        const float mean = group_sum<LPR>(s) / (float)D;
+        float var = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float t = x[j][k] - mean; var += t * t; }
+        const float rstd = 1.0f / sqrtf(group_sum<LPR>(var) / (float)D + eps);
+        float s1 = 0.f, s2 = 0.f;                                  // mean(gamma g'), mean(gamma g' xhat)
+        f32x4 gg[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (x[j][k] - mean) * rstd;
+                gg[j][k] = go[j][k] * gam[j][k];
+                s1 += gg[j][k];
+                s2 += gg[j][k] * xh;
+                if (ok) { dg[j][k] += go[j][k] * xh; db[j][k] += go[j][k]; }
+                x[j][k] = xh;
+            }
+        s1 = group_sum<LPR>(s1) / (float)D;
+        s2 = group_sum<LPR>(s2) / (float)D;
+        const int deg = indeg[v];
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            f32x4 dp, gv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dx = rstd * (gg[j][k] - s1 - x[j][k] * s2);
+                dp[k] = pre[j][k] > 0.f ? dx * dm[j][k] : 0.f;
+                gv[k] = dp[k] * inv;
+                mx = fmaxf(mx, fabsf(gv[k]));
+            }
+            if (ok) {
+                *(f32x4*)(dpre + row + 4 * (j * LPR + cl)) = dp;
+                *(f32x4*)(G + row + 4 * (j * LPR + cl)) = gv;
+            }
+            x[j] = gv;
+        }
+        if (Gs) {                                                  // as split2h_rows_kernel (message_hx.hip) cuts a row
+            const int sh = split2h_shift(group_absmax<LPR>(mx));
+            const float up = pow2f(sh);
+            float tiny = 0.f, nz = 0.f;
+            _Float16* __restrict__ dst = (_Float16*)(Gs + (size_t)v * (4 * (size_t)D));
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                tb_f16x4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xs = x[j][k] * up;
+                    _Float16 a, b;
+                    split2h(xs, a, b);
+                    hi[k] = a;
+                    lo[k] = b;
+                    tiny += range_tiny(xs) ? 1.f : 0.f;
+                    nz += xs != 0.f ? 1.f : 0.f;
+                }
+                if (ok) {
+                    *(tb_f16x4*)(dst + 4 * (j * LPR + cl)) = hi;
+                    *(tb_f16x4*)(dst + D + 4 * (j * LPR + cl)) = lo;
+                }
+            }
+            tiny = group_sum<LPR>(tiny);
+            nz = group_sum<LPR>(nz);
+            if (ok && cl == 0) {
+                *(float*)(Gs + (size_t)N * (4 * (size_t)D) + (size_t)v * 4) = pow2f(-sh);
+                range_raise(range_flag, GHF_RANGE_ROWS, (int)tiny, (int)nz);
+            }
+        }
+    }
+    // the wave's row groups, then the workgroup's waves, in order
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = dg[j][k], b = db[j][k];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                a += __shfl_xor(a, o);
+                b += __shfl_xor(b, o);
+            }
+            if (sub == 0) {
+                red[wave][0][4 * (j * LPR + cl) + k] = a;
+                red[wave][1][4 * (j * LPR + cl) + k] = b;
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const float* r = &red[0][0][0] + i;
+        part[(size_t)blockIdx.x * (2 * D) + i] = ((r[0] + r[2 * D]) + r[4 * D]) + r[6 * D];
+    }
+}
+
+// any d <= BW_MAX_D: one wave per row, columns lane + 64 c
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ agg,
                                                        const float* __restrict__ h, const float* __restrict__ gamma, float eps,
                                                        const int32_t* __restrict__ indeg, int64_t N, int d,
-                                                       float* __restrict__ dpre, float* __restrict__ G, float* __restrict__ T,
+                                                       float* __restrict__ dpre, float* __restrict__ G, float* __restrict__ part,
                                                        const float* __restrict__ drop) {
-    const int lane = threadIdx.x & 63;
-    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= N) return;
-    float pre[BW_PER_LANE], x[BW_PER_LANE], gg[BW_PER_LANE], dm[BW_PER_LANE];   // dm: the dropout mask (scaled; 1 without dropout)
-    float s = 0.f;
+    extern __shared__ float tb_red[];                            // [4][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[BW_PER_LANE], db[BW_PER_LANE];
+#pragma unroll
+    for (int c = 0; c < BW_PER_LANE; ++c) dg[c] = db[c] = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < N; v += (int64_t)gridDim.x * 4) {
+        float pre[BW_PER_LANE], x[BW_PER_LANE], gg[BW_PER_LANE], dm[BW_PER_LANE];   // dm: the dropout mask (scaled; 1 without dropout)
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < BW_PER_LANE; ++c) {
+            const int o = lane + 64 * c;
+            pre[c] = x[c] = gg[c] = 0.f;
+            dm[c] = 1.f;
+            if (o < d) {
+                pre[c] = agg[(size_t)v * d + o] + h[(size_t)v * d + o];
+                if (drop) dm[c] = drop[(size_t)v * d + o];
+                x[c] = fmaxf(pre[c], 0.f) * dm[c];
+                s += x[c];
+            }
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < BW_PER_LANE; ++c)
+            if (lane + 64 * c < d) { const float t = x[c] - mean; var += t * t; }
+        const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
+        float s1 = 0.f, s2 = 0.f;                            // mean(gamma g'), mean(gamma g' xhat)
+#pragma unroll
+        for (int c = 0; c < BW_PER_LANE; ++c) {
+            const int o = lane + 64 * c;
+            if (o < d) {
+                const float go = g_out[(size_t)v * d + o], xh = (x[c] - mean) * rstd;
+                gg[c] = go * gamma[o];
+                s1 += gg[c];
+                s2 += gg[c] * xh;
+                dg[c] += go * xh;
+                db[c] += go;
+                x[c] = xh;
+            }
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+        const int deg = indeg[v];
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+#pragma unroll
+        for (int c = 0; c < BW_PER_LANE; ++c) {
+            const int o = lane + 64 * c;
+            if (o < d) {
+                const float dx = rstd * (gg[c] - s1 - x[c] * s2);
+                const float dp = pre[c] > 0.f ? dx * dm[c] : 0.f;
+                dpre[(size_t)v * d + o] = dp;
+                G[(size_t)v * d + o] = dp * inv;
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < BW_PER_LANE; ++c) {
         const int o = lane + 64 * c;
-        pre[c] = x[c] = gg[c] = 0.f;
-        dm[c] = 1.f;
         if (o < d) {
-            pre[c] = agg[(size_t)v * d + o] + h[(size_t)v * d + o];
-            if (drop) dm[c] = drop[(size_t)v * d + o];
-            x[c] = fmaxf(pre[c], 0.f) * dm[c];
-            s += x[c];
+            tb_red[(wave * 2 + 0) * d + o] = dg[c];
+            tb_red[(wave * 2 + 1) * d + o] = db[c];
         }
     }
-    const float mean = wave_sum(s) / (float)d;
-    float var = 0.f;
-#pragma unroll
-    for (int c = 0; c < BW_PER_LANE; ++c)
-        if (lane + 64 * c < d) { const float t = x[c] - mean; var += t * t; }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
-    float s1 = 0.f, s2 = 0.f;                            // mean(gamma g'), mean(gamma g' xhat)
-#pragma unroll
-    for (int c = 0; c < BW_PER_LANE; ++c) {
-        const int o = lane + 64 * c;
-        if (o < d) {
-            const float go = g_out[(size_t)v * d + o], xh = (x[c] - mean) * rstd;
-            gg[c] = go * gamma[o];
-            s1 += gg[c];
-            s2 += gg[c] * xh;
-            T[(size_t)v * d + o] = go * xh;
-            x[c] = xh;
-        }
-    }
-    s1 = wave_sum(s1) / (float)d;
-    s2 = wave_sum(s2) / (float)d;
-    const int deg = indeg[v];
-    const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
-#pragma unroll
-    for (int c = 0; c < BW_PER_LANE; ++c) {
-        const int o = lane + 64 * c;
-        if (o < d) {
-            const float dx = rstd * (gg[c] - s1 - x[c] * s2);
-            const float dp = pre[c] > 0.f ? dx * dm[c] : 0.f;
-            dpre[(size_t)v * d + o] = dp;
-            G[(size_t)v * d + o] = dp * inv;
-        }
-    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * d; i += 256)
+        part[(size_t)blockIdx.x * (2 * d) + i] = ((tb_red[i] + tb_red[2 * d + i]) + tb_red[4 * d + i]) + tb_red[6 * d + i];
 }
 
 // out[o] = sum_v X[v][o] * (mask ? (mask[v][o] > 0) : 1): a tree of fixed shape.  One pass cuts the rows into runs of
@@ -584,13 +764,47 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __r
     }
 }
 
+static int64_t tail_bwd_blocks(int64_t N) { const int64_t b = cdiv(N, 4); return b < TB_MAX_BLOCKS ? (b > 0 ? b : 1) : TB_MAX_BLOCKS; }
+
+size_t colsum_workspace_floats(int64_t N, int d);
+size_t tail_bwd_workspace_floats(int64_t N, int d) {          // the workgroups' partial sums + their colsum's levels
+    const int64_t nb = tail_bwd_blocks(N);
+    return (size_t)nb * 2 * d + colsum_workspace_floats(nb, 2 * d);
+}
+
 int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const float* gamma, float eps, const int32_t* indeg,
-                    int64_t N, int d, float* dpre, float* G, float* T, const float* drop, hipStream_t stream) {
+                    int64_t N, int d, float* dpre, float* G, void* G_split, float* dgb, float* workspace, const float* drop,
+                    hipStream_t stream) {
     GHF_REQUIRE(d >= 1 && d <= BW_MAX_D, "tail_bwd: d=%d outside [1,%d]", d, BW_MAX_D);
-    if (N <= 0) return GHF_OK;
-    tail_bwd_kernel<<<(unsigned)cdiv(N, 4), 256, 0, stream>>>(g_out, agg, h, gamma, eps, indeg, N, d, dpre, G, T, drop);
+    if (N <= 0) {
+        GHF_HIP_CHECK(hipMemsetAsync(dgb, 0, sizeof(float) * 2 * d, stream));
+        return GHF_OK;
+    }
+    const unsigned nb = (unsigned)tail_bwd_blocks(N);
+    float* part = workspace;
+    const bool a16 = ((((uintptr_t)g_out | (uintptr_t)agg | (uintptr_t)h | (uintptr_t)gamma | (uintptr_t)dpre | (uintptr_t)G |
+                       (uintptr_t)drop | (uintptr_t)G_split) & 15) == 0);
+    bool split_done = false;
+#define GHF_TB_V4(LPR, NV)                                                                                                      \
+    do {                                                                                                                        \
+        tail_bwd_v4_kernel<LPR, NV><<<nb, 256, 0, stream>>>(g_out, agg, h, gamma, eps, indeg, N, dpre, G, (char*)G_split, part, \
+                                                            drop, range_flag_ptr());                                            \
+        split_done = true;                                                                                                      \
+    } while (0)
+    if (a16 && d == 32) GHF_TB_V4(8, 1);
+    else if (a16 && d == 64) GHF_TB_V4(16, 1);
+    else if (a16 && d == 128) GHF_TB_V4(32, 1);
+    else if (a16 && d == 256) GHF_TB_V4(64, 1);
+    else if (a16 && d == 512) GHF_TB_V4(64, 2);
+    else if (a16 && d == 1024) GHF_TB_V4(64, 4);
+    else tail_bwd_kernel<<<nb, 256, sizeof(float) * 8 * d, stream>>>(g_out, agg, h, gamma, eps, indeg, N, d, dpre, G, part, drop);
+#undef GHF_TB_V4
     GHF_LAUNCH_CHECK();
-    return GHF_OK;
+    if (G_split && !split_done) {
+        const int rc = launch_split2h_rows(G, N, d, 0, N, G_split, stream);
+        if (rc != GHF_OK) return rc;
+    }
+    return launch_colsum(part, nullptr, nb, 2 * d, workspace + (size_t)nb * 2 * d, dgb, 0, stream);
 }
 
 

@@ -196,10 +196,14 @@ int ghf_group_edges(const int64_t* rel_id, int64_t E, int R, void* workspace, si
     return launch_group_edges(rel_id, E, R, workspace, workspace_bytes, perm, goff, (hipStream_t)stream);
 }
 
+size_t ghf_tail_bwd_workspace_floats(int64_t N, int d) { return (N >= 0 && d > 0) ? tail_bwd_workspace_floats(N, d) : 0; }
+
 int ghf_tail_bwd(const float* grad_out, const float* agg, const float* h, const float* ln_gamma, float ln_eps,
-                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, const float* drop, void* stream) {
-    GHF_REQUIRE(grad_out && agg && h && ln_gamma && indeg && dpre && G && T, "tail_bwd: null pointer argument");
-    return launch_tail_bwd(grad_out, agg, h, ln_gamma, ln_eps, indeg, N, d, dpre, G, T, drop, (hipStream_t)stream);
+                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, void* G_split, float* dgamma_dbeta,
+                 float* workspace, const float* drop, void* stream) {
+    GHF_REQUIRE(grad_out && agg && h && ln_gamma && indeg && dpre && G && dgamma_dbeta && workspace, "tail_bwd: null pointer argument");
+    return launch_tail_bwd(grad_out, agg, h, ln_gamma, ln_eps, indeg, N, d, dpre, G, G_split, dgamma_dbeta, workspace, drop,
+                           (hipStream_t)stream);
 }
 
 size_t ghf_colsum_workspace_floats(int64_t N, int d) { return colsum_workspace_floats(N, d); }

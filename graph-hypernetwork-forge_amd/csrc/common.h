@@ -170,7 +170,9 @@ int launch_group_edges(const int64_t* rel, int64_t E, int R, void* ws, size_t ws
                        hipStream_t stream);
 // backward.hip
 int launch_tail_bwd(const float* g_out, const float* agg, const float* h, const float* gamma, float eps, const int32_t* indeg,
-                    int64_t N, int d, float* dpre, float* G, float* T, const float* drop, hipStream_t stream);
+                    int64_t N, int d, float* dpre, float* G, void* G_split, float* dgb, float* workspace, const float* drop,
+                    hipStream_t stream);
+size_t tail_bwd_workspace_floats(int64_t N, int d);
 size_t colsum_workspace_floats(int64_t N, int d);
 int launch_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, hipStream_t stream);
 int launch_relu_mask(const float* X, const float* ref, int64_t n, float* out, hipStream_t stream);

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 10
+#define GHF_ABI_VERSION 11
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -242,8 +242,11 @@ int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* deg_
 
 /* ---- backward of the path (the reference trains through it with autograd: demo.py:79-101) ----------
  * With out_v = (1/c_v) sum_e(h_u Wm[r] + b[r] + h_v Ws[r]), x = relu(out + h), h' = LayerNorm(x), g' = dL/dh':
- *   ghf_tail_bwd   : dpre = dL/d(out+h) (also the residual's share of dL/dh), G_v = dpre_v / c_v, T = g' * xhat
- *                    (dgamma = colsum(T), dbeta = colsum(g'));  agg is the forward's GHF_FLAG_NO_TAIL output
+ *   ghf_tail_bwd   : dpre = dL/d(out+h) (also the residual's share of dL/dh), G_v = dpre_v / c_v, and the LayerNorm's
+ *                    dgamma_dbeta [2][d] = (sum_v g'_v * xhat_v, sum_v g'_v), summed in a fixed order on the way;  agg is the
+ *                    forward's GHF_FLAG_NO_TAIL output (or agg_out).  G_split (optional): also G in the form ghf_split_rows
+ *                    (GHF_WLAYOUT_SPLIT2H) would cut from it, for the gradient passes that gather G.  workspace:
+ *                    ghf_tail_bwd_workspace_floats(N, d) floats
  *   ghf_group_outer: C[g][i][o] (+)= sum_{e in gstart[g]..gend[g]} A[ia[e]][i] * B[ib[e]][o]; ia / ib NULL = e itself,
  *                    da == 0: A = 1 (C is [ngroups][1][db]).  dWm[r] = sum h_u^T G_v, dWs[r], db[r], and the Linear
  *                    layers' weight gradients.  Summation order fixed: reproducible.
@@ -256,8 +259,10 @@ int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* deg_
 size_t ghf_group_workspace_bytes(int64_t E);
 int ghf_group_edges(const int64_t* rel_id, int64_t E, int R, void* workspace, size_t workspace_bytes,
                     int64_t* perm, int64_t* goff, void* stream);
+size_t ghf_tail_bwd_workspace_floats(int64_t N, int d);
 int ghf_tail_bwd(const float* grad_out, const float* agg, const float* h, const float* ln_gamma, float ln_eps,
-                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, float* T, const float* drop /* [N,d] or NULL */, void* stream);
+                 const int32_t* indeg, int64_t N, int d, float* dpre, float* G, void* G_split /* or NULL */,
+                 float* dgamma_dbeta /* [2][d] */, float* workspace, const float* drop /* [N,d] or NULL */, void* stream);
 size_t ghf_colsum_workspace_floats(int64_t N, int d);
 int ghf_colsum(const float* X, const float* mask, int64_t N, int d, float* workspace, float* out, int accumulate, void* stream);
 int ghf_relu_mask(const float* X, const float* ref, int64_t n, float* out, void* stream);

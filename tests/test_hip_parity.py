@@ -487,6 +487,38 @@ def test_side_output_and_zero_half_flags(N, E, R, kind):
         _native.message_layer_fwd(other, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, out, h_split=hs, flags=_native.GHF_FLAG_ADD_H)
 
 
+@pytest.mark.parametrize("d,N", [(20, 301), (32, 77), (64, 1000), (128, 1), (128, 9001), (256, 2050), (384, 130), (512, 300), (1024, 70)])
+@pytest.mark.parametrize("dropping", [False, True])
+def test_tail_bwd_outputs(d, N, dropping):
+    """ghf_tail_bwd against float64 autograd of the tail (reference hypergnn.py:288-296): dpre, G = dpre / c, the LayerNorm's
+    dgamma / dbeta summed inside the launch, and G in the two-piece form — the pieces and scales ghf_split_rows cuts from G."""
+    g = torch.Generator().manual_seed(100 * d + N)
+    agg, h, go = (torch.randn(N, d, generator=g) for _ in range(3))
+    gamma = torch.rand(d, generator=g) + 0.5
+    indeg = torch.randint(0, 6, (N,), generator=g, dtype=torch.int32)
+    drop = ((torch.rand(N, d, generator=g) < 0.75).float() / 0.75) if dropping else None
+    pre = (agg.double() + h.double()).requires_grad_(True)
+    gam = gamma.double().requires_grad_(True)
+    bet = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+    x = torch.relu(pre) * (drop.double() if dropping else 1.0)
+    torch.nn.functional.layer_norm(x, (d,), gam, bet, 1e-5).backward(go.double())
+    dev = lambda a: a.to(DEV)                                                              # noqa: E731
+    splittable = d in (64, 128) or d % 128 == 0
+    dpre, G, Gs, dgamma, dbeta = _native.tail_bwd(dev(go), dev(agg), dev(h), dev(gamma), 1e-5, dev(indeg), drop=None if drop is None else dev(drop),
+                                                  split_layout=_native.WLAYOUT_SPLIT2H if splittable else None)
+    assert_close(dpre.cpu().numpy(), pre.grad.float().numpy(), "dpre")
+    torch.testing.assert_close(G, dpre / dev(indeg).clamp(min=1).float().unsqueeze(1), rtol=3e-7, atol=0.0)    # (the kernel multiplies by 1/c)
+    scale = float(N) ** 0.5                                                                 # the column sums grow like sqrt(N)
+    assert_close(dgamma.cpu().numpy() / scale, gam.grad.float().numpy() / scale, "dgamma")
+    assert_close(dbeta.cpu().numpy() / scale, bet.grad.float().numpy() / scale, "dbeta")
+    if splittable:
+        ref = _native.split_rows(G, _native.WLAYOUT_SPLIT2H)                # equal as numbers (a dropped entry's zero keeps its sign here)
+        assert torch.equal(Gs[:2 * N * d].view(torch.float16), ref[:2 * N * d].view(torch.float16))
+        assert torch.equal(Gs[2 * N * d:], ref[2 * N * d:])                                # the rows' scales
+    else:
+        assert Gs is None
+
+
 @pytest.mark.parametrize("d,N,E,R,kind", [(20, 300, 2500, 5, "powerlaw"), (128, 1200, 9000, 6, "uniform"),
                                           (128, 500, 6000, 3, "powerlaw"), (64, 1500, 14000, 6, "uniform"),
                                           (64, 700, 9000, 3, "powerlaw")])
