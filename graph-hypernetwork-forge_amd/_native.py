@@ -650,7 +650,7 @@ def dot(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     n = X.numel()
     if Y.numel() != n:
         raise ValueError("dot: operands differ in size")
-    ws = torch.empty((n + 65535) // 65536, dtype=torch.float32, device=X.device)
+    ws = torch.empty((n + 8191) // 8192, dtype=torch.float32, device=X.device)
     out = torch.empty(1, dtype=torch.float32, device=X.device)
     _check(load().ghf_dot(_ptr(X), _ptr(Y), n, _ptr(ws), _ptr(out), _stream()), "ghf_dot")
     return out

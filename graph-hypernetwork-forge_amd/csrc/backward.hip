@@ -334,7 +334,25 @@ __global__ __launch_bounds__(256) void group_outer_kernel(const float* __restric
     f32x4 acc[NTB];
 #pragma unroll
     for (int t = 0; t < NTB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int64_t e = w0; e < w1; e += 4) {
+    int64_t e = w0;
+    if (da > 0 && it * 16 + 16 <= da && o_base + 16 * NTB <= db) {      // whole tiles (a wave-uniform test): four steps' loads in flight, the same chain of MFMAs
+        for (; e + 16 <= w1; e += 16) {
+            float a[4], b[4][NTB];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t ek = e + 4 * u + q;
+                a[u] = A[(size_t)(ia ? ia[ek] : ek) * da + i];
+                const float* __restrict__ br = B + (size_t)(ib ? ib[ek] : ek) * db + o_base + c16;
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) b[u][t] = br[16 * t];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NTB; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][t], acc[t], 0, 0, 0);
+        }
+    }
+    for (; e < w1; e += 4) {
         const int64_t ek = e + q;                         // this lane's edge for both fragments
         const bool ok = ek < w1;
         float a = 0.f;
@@ -535,11 +553,28 @@ typedef _Float16 eo_f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 eo_f16x8 __attribute__((ext_vector_type(8)));
 typedef short eo_s16x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
-    float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+// out[y] = bits of max |x_y[i]| for the two tensors y = blockIdx.y (a maximum: any order gives the same bits)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int64_t n,
+                                                     unsigned* __restrict__ out) {
+    const float* __restrict__ x = blockIdx.y ? x1 : x0;
+    const int64_t n4 = ((uintptr_t)x & 15) == 0 ? n / 4 : 0, stride = (int64_t)gridDim.x * 256;
+    const f32x4* __restrict__ x4 = (const f32x4*)x;
+    f32x4 m4 = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {            // four 16-byte loads in flight per lane
+        const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], e = x4[i + 3 * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m4[k] = fmaxf(fmaxf(m4[k], fmaxf(fabsf(a[k]), fabsf(b[k]))), fmaxf(fabsf(c[k]), fabsf(e[k])));
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 a = x4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m4[k] = fmaxf(m4[k], fabsf(a[k]));
+    }
+    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = fmaxf(m, fabsf(x[j]));
     m = wave_absmax(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));          // (non-negative floats order as their bits)
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + blockIdx.y, __float_as_uint(m));   // (non-negative floats order as their bits)
 }
 
 __device__ __forceinline__ unsigned eo_off(int row, int ch) { return 256u * row + 16u * (unsigned)(ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -717,8 +752,7 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
         GHF_REQUIRE(N > 0, "edge_outer: N (rows of h and G) must be given");
         GHF_HIP_CHECK(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), stream));
         const unsigned ag = (unsigned)(cdiv(N * d, 256 * 16) < 2048 ? cdiv(N * d, 256 * 16) : 2048);
-        absmax_kernel<<<ag, 256, 0, stream>>>(h, N * d, amax);
-        absmax_kernel<<<ag, 256, 0, stream>>>(G, N * d, amax + 1);
+        absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h, G, N * d, amax);
         GHF_LAUNCH_CHECK();
     }
     for (int rb = 0; rb < d / D; ++rb)                     // tile rows 2D*rb ..: two D-column pieces of [h_src | h_dst]
@@ -855,29 +889,29 @@ int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B
     return GHF_OK;
 }
 
-// out[0] = sum_i X[i] * Y[i], two deterministic stages (workspace: cdiv(n, 65536) floats)
+// out[0] = sum_i X[i] * Y[i], two deterministic stages (workspace: cdiv(n, 8192) floats)
+constexpr int64_t DOT_BLOCK = 8192;                      // elements per workgroup of the first stage
 __global__ __launch_bounds__(256) void dot_stage1_kernel(const float* __restrict__ X, const float* __restrict__ Y, int64_t n,
                                                          float* __restrict__ part) {
     __shared__ float red[4];
-    const int64_t b0 = (int64_t)blockIdx.x * 65536;
+    const int64_t b0 = (int64_t)blockIdx.x * DOT_BLOCK;
     float s = 0.f;
-    for (int64_t i = b0 + threadIdx.x; i < b0 + 65536 && i < n; i += 256) s = fmaf(X[i], Y[i], s);
+    for (int64_t i = b0 + threadIdx.x; i < b0 + DOT_BLOCK && i < n; i += 256) s = fmaf(X[i], Y[i], s);
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
-__global__ void dot_stage2_kernel(const float* __restrict__ part, int64_t nblk, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = 0.f;
-        for (int64_t b = 0; b < nblk; ++b) s += part[b];
-        out[0] = s;
-    }
+__global__ __launch_bounds__(64) void dot_stage2_kernel(const float* __restrict__ part, int64_t nblk, float* __restrict__ out) {
+    float s = 0.f;                                           // one wave: lane l adds blocks l, l + 64, ... in order
+    for (int64_t b = threadIdx.x; b < nblk; b += 64) s += part[b];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream) {
     GHF_REQUIRE(n > 0, "dot: empty input");
-    const int64_t nblk = cdiv(n, 65536);
+    const int64_t nblk = cdiv(n, DOT_BLOCK);
     dot_stage1_kernel<<<(unsigned)nblk, 256, 0, stream>>>(X, Y, n, workspace);
     GHF_LAUNCH_CHECK();
     dot_stage2_kernel<<<1, 64, 0, stream>>>(workspace, nblk, out);

@@ -126,26 +126,37 @@ __global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__
 }
 
 // Second stage for split destination blocks (hubs): sum the block's partial slots in a fixed order (reproducible), then
-// the K3 tail.  One workgroup per (block, COMB_ROWS destination rows) of the row range — a hub block's hundred-odd
-// slots are then read by 27 workgroups with four loads in flight per lane instead of by one workgroup's serial
-// chain (power-law C3: 4.7 ms -> 0.1 ms); blocks with a single item return at once.  One wave per destination row,
-// lanes stride the columns.
+// the K3 tail.  One workgroup per COMB_ROWS destination rows of a split block — a hub block's hundred-odd
+// slots are then read by dozens of workgroups with four loads in flight per lane instead of by one workgroup's serial
+// chain (power-law C3: 4.7 ms -> 0.1 ms).  The grid covers the split blocks only: (items beyond one per block) x (row
+// groups of a block), each workgroup finding its block by bisection (a grid over all blocks cost 77 us per launch at
+// BASELINE config 3, where only the last round's 45 blocks are split).  One wave per destination row, lanes stride
+// the columns.
 constexpr int COMB_MAX_PER_LANE = GEN_MAX_D / 64;
 constexpr int COMB_ROWS = 8;
 __global__ __launch_bounds__(256) void combine_split_kernel(
     const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off,
     const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
-    const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int64_t row_end,
+    const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int nblk, int64_t row_end,
     float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail, int32_t* __restrict__ range_flag,
     float* __restrict__ agg_out) {
-    const int64_t blk = blk0 + blockIdx.x;
+    // blockIdx.x numbers the range's items beyond one per block: a block of k items owns k - 1 of them, found by bisection
+    // on f(b) = (items before block b) - b; its row groups go round these k - 1 workgroup columns
+    int lo = 0, hi = nblk - 1;
+    const int base = blk_item_off[blk0];
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk_item_off[blk0 + mid] - base - mid <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t blk = blk0 + lo;
     const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
     if (i1 - i0 <= 1) return;
     const int slot0 = item_tab[4 * (size_t)i0 + 3], nslots = i1 - i0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t node0 = blk * BN;
     const int nrows_blk = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
-    const int vbase = (int)blockIdx.y * COMB_ROWS;
+    const int vbase = ((int)blockIdx.y * (nslots - 1) + ((int)blockIdx.x - (i0 - base - lo))) * COMB_ROWS;
+    if (vbase >= nrows_blk) return;
     const int nrows = nrows_blk < vbase + COMB_ROWS ? nrows_blk : vbase + COMB_ROWS;
     for (int v = vbase + w; v < nrows; v += 4) {
         const int64_t node = node0 + v;
@@ -224,9 +235,12 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
 
 int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const int64_t blk0 = a.row0 / a.block_nodes, row_end = a.row0 + a.rows;
-    const dim3 grid((unsigned)cdiv(a.rows, a.block_nodes), (unsigned)cdiv(a.block_nodes, COMB_ROWS));
+    const int64_t nblk = cdiv(a.rows, a.block_nodes), extra = a.n_items - nblk;     // items beyond one per block
+    if (extra <= 0) return GHF_OK;
+    GHF_REQUIRE(extra < (1ll << 31), "combine_split: too many work items");
+    const dim3 grid((unsigned)extra, (unsigned)cdiv(a.block_nodes, COMB_ROWS));
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
-                                                   a.ln_eps, a.N, a.d, a.block_nodes, blk0, row_end, a.h_out, a.h_split_out, a.wlayout,
+                                                   a.ln_eps, a.N, a.d, a.block_nodes, blk0, (int)nblk, row_end, a.h_out, a.h_split_out, a.wlayout,
                                                    a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);
     GHF_LAUNCH_CHECK();
     return GHF_OK;

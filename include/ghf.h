@@ -289,7 +289,7 @@ int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int
 int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream);
 int ghf_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
 int ghf_rowscale(const float* X, const float* g, int64_t n, int d, float* out, void* stream);
-/* out[0] = sum_i X[i] Y[i] (fixed order); workspace: (n + 65535) / 65536 floats */
+/* out[0] = sum_i X[i] Y[i] (fixed order); workspace: (n + 8191) / 8192 floats */
 int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, void* stream);
 /* Hidden activations of the weight generator's three heads (what its backward needs besides the outputs):
  * acts[head][layer][r][Hh], layer = 0 .. num_hidden-1 (post-ReLU).  Same head_params as ghf_weightgen_fwd. */
