@@ -39,6 +39,10 @@ for _k in ("U", "UW", "CR", "SB", "RD", "AD", "PK", "YT", "PRIO", "LATE", "DEFER
     _g = _re.search(r"bx%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX_%s=%s" % (_k, _g.group(1)))
+for _k in ("U", "CR"):                                  # message_bx.hip, hidden 64: e.g. GHF_VARIANT=b64U3_b64CR128
+    _g = _re.search(r"b64%s(\d+)" % _k, VARIANT)
+    if _g:
+        FLAGS.append("-DGHF_BX64_%s=%s" % (_k, _g.group(1)))
 if "eoslow" in VARIANT:
     FLAGS.append("-DGHF_EO_SLOW_FRAG")                  # debug: edge_outer_h fragments read element by element
 _m = _re.search(r"(?<!bx)exp(\d+)", VARIANT)

@@ -146,6 +146,12 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_CR
 #define GHF_BX_CR 76         // rows per chunk
 #endif
+#ifndef GHF_BX64_U
+#define GHF_BX64_U 2         // hidden 64: units per helper lane (block of 128 U nodes) and rows per chunk
+#endif
+#ifndef GHF_BX64_CR
+#define GHF_BX64_CR 112
+#endif
 
 // Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals per segment.
 // consumers: 0 barrier wait, 1 phase-0 stage, 2 phase-1 stage, 3 staging writes
@@ -185,7 +191,7 @@ template <> struct BxCfg<128> {
 // long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block (two units per helper
 // lane) so that C2's 100 k nodes still make 391 workgroups for 256 CUs
 template <> struct BxCfg<64> {
-    static constexpr int U = 2, UW = 32, CR = 112;
+    static constexpr int U = GHF_BX64_U, UW = 32, CR = GHF_BX64_CR;
     static constexpr int BN = 4 * U * UW;          // 256 lanes x U units x UW positions / 64
     static constexpr int MTC = (CR + 15) / 16;
     static constexpr bool YT = false;
