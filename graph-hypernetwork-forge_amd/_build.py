@@ -43,6 +43,9 @@ for _k in ("U", "CR"):                                  # message_bx.hip, hidden
     _g = _re.search(r"b64%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX64_%s=%s" % (_k, _g.group(1)))
+_i = _re.search(r"ipexp(\d+)", VARIANT)
+if _i:
+    FLAGS.append("-DGHF_IPEXP=" + _i.group(1))          # input_proj.hip timing experiments
 if "eoslow" in VARIANT:
     FLAGS.append("-DGHF_EO_SLOW_FRAG")                  # debug: edge_outer_h fragments read element by element
 _m = _re.search(r"(?<!bx)exp(\d+)", VARIANT)

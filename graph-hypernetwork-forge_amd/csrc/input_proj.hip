@@ -17,6 +17,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 ip_f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int IP_MT = 2;       // m-tiles (16 rows each) per wave
+#ifndef GHF_IPEXP
+#define GHF_IPEXP 0           // timing experiments only (GHF_VARIANT=ipexp<mask>): 1 no fp32 stores, 2 no piece stores, 4 no range guard
+#endif
 
 // SPLIT: also write the rows in GHF_WLAYOUT_SPLIT2H form (ghf_split_rows) for the first message layer's gathers: a row
 // lives in the four lanes {c16, c16 + 16, c16 + 32, c16 + 48}, so its largest magnitude is two lane exchanges away.
@@ -115,9 +118,10 @@ __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __res
         }
         if (r < N) {
             float* __restrict__ o = h0 + (size_t)r * D + 4 * q;
+            if (!(GHF_IPEXP & 1))
 #pragma unroll
-            for (int t = 0; t < NT; ++t) *(f32x4*)(o + 16 * t) = v[t];
-            if (SPLIT) {
+                for (int t = 0; t < NT; ++t) *(f32x4*)(o + 16 * t) = v[t];
+            if (SPLIT && !(GHF_IPEXP & 2)) {
                 _Float16* __restrict__ sp = (_Float16*)(h_split + (size_t)r * (4 * D)) + 4 * q;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void input_proj_mfma_kernel(const float* __res
                 }
             }
         }
-        if (SPLIT) {                                      // range guard (common.h); all lanes take part in the reduction
+        if (SPLIT && !(GHF_IPEXP & 4)) {                  // range guard (common.h); all lanes take part in the reduction
             float tiny = 0.f, nz = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
