@@ -146,6 +146,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_CR
 #define GHF_BX_CR 76         // rows per chunk
 #endif
+#ifndef GHF_BX_TGB
+#define GHF_BX_TGB 3         // tail: four-row groups in flight per wave (six per half at d = 128); measured 1: 3.21, 2: 3.23, 3: 3.18, 4: 3.27 ms
+#endif
 #ifndef GHF_BX64_U
 #define GHF_BX64_U 2         // hidden 64: units per helper lane (block of 128 U nodes) and rows per chunk
 #endif
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 tail_half(0, std::integral_constant<int, 1>{});      // (the other half of the sums is still in registers)
                 BX_STAMP(6);
             } else {
-                tail_half(1, std::integral_constant<int, 3>{});
+                tail_half(1, std::integral_constant<int, GHF_BX_TGB>{});
                 BX_STAMP(7);
             }
         }
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         for (int half = 0; half < 2; ++half) {
             __syncthreads();
             __syncthreads();
-            tail_half(half, std::integral_constant<int, 3>{});
+            tail_half(half, std::integral_constant<int, GHF_BX_TGB>{});
             if (half == 0) BX_STAMP(6);
         }
         BX_STAMP(6);
