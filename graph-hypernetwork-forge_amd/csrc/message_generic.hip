@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__
 // the K3 tail.  One workgroup per COMB_ROWS destination rows of a split block — a hub block's hundred-odd
 // slots are then read by dozens of workgroups with four loads in flight per lane instead of by one workgroup's serial
 // chain (power-law C3: 4.7 ms -> 0.1 ms).  The grid covers the split blocks only: (items beyond one per block) x (row
-// groups of a block), each workgroup finding its block by bisection (a grid over all blocks cost 77 us per launch at
+// groups of a block), each workgroup finding its block by a 64-way search (a grid over all blocks cost 77 us per launch at
 // BASELINE config 3, where only the last round's 45 blocks are split).  One wave per destination row, lanes stride
 // the columns.
 constexpr int COMB_MAX_PER_LANE = GEN_MAX_D / 64;
@@ -142,11 +142,15 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
     float* __restrict__ agg_out) {
     // blockIdx.x numbers the range's items beyond one per block: a block of k items owns k - 1 of them, found by bisection
     // on f(b) = (items before block b) - b; its row groups go round these k - 1 workgroup columns
-    int lo = 0, hi = nblk - 1;
+    // (64 probes per step, one per lane: two or three dependent loads instead of a bisection's twelve)
     const int base = blk_item_off[blk0];
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (blk_item_off[blk0 + mid] - base - mid <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    int lo = 0;
+    for (int span = nblk; span > 1;) {                    // the block is in [lo, lo + span)
+        const int step = (span + 63) >> 6, probe = (int)(threadIdx.x & 63) * step;
+        const bool le = probe < span && blk_item_off[blk0 + lo + probe] - base - (lo + probe) <= (int)blockIdx.x;
+        const int l1 = 63 - __builtin_clzll(__ballot(le));             // f is monotone and f(lo) <= blockIdx.x: the set lanes are a prefix
+        lo += l1 * step;
+        span = span - l1 * step < step ? span - l1 * step : step;
     }
     const int64_t blk = blk0 + lo;
     const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
