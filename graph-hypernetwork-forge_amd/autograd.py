@@ -26,6 +26,7 @@ i.e. ``ghf_group_outer`` again (``_native.matmul_tn``).
 
 from __future__ import annotations
 
+import os
 import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -136,6 +137,17 @@ class _SplitCarry:
         self.ref, self.version, self.split = weakref.ref(h), h._version, split
 
 
+_EO_SIDE = os.environ.get("GHF_EO_SIDE", "1") != "0"          # (C3 training step 49.1 -> 48.7 ms)
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    key = torch.device(device).index or 0
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class MessageLayerFn(torch.autograd.Function):
     """One HyperGNN layer (reference hypergnn.py:281-296) with per-relation weights in natural layout."""
 
@@ -174,8 +186,18 @@ class MessageLayerFn(torch.autograd.Function):
                    and plan.block_nodes > 1)
         dpre, G, Gs, dgamma, dbeta = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg, drop=ctx.drop,
                                                       split_layout=plan.wlayout if split_G else None)
+        side = None
         if tp.slice_tab is not None:
-            dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
+            if _EO_SIDE and ctx.needs_input_grad[0]:
+                # the weight gradients (bound by their row gathers) beside the two gradient passes (bound inside the CU): two
+                # streams, joined before the results leave
+                main = torch.cuda.current_stream(h.device)
+                side = _side_stream(h.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
+            else:
+                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
             d = h.size(1)
             dWm, dWs = dW[:, :d], dW[:, d:]
         else:
@@ -194,6 +216,10 @@ class MessageLayerFn(torch.autograd.Function):
             else:
                 dh = _native.add3(dpre, _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs),
                                   _raw_message(G, tp.rev, Wr, Wr2, zero_b, _native.GHF_FLAG_ZERO_DST, Gs), out=dpre)
+        if side is not None:
+            main.wait_stream(side)
+            dW.record_stream(main)
+            db.record_stream(main)
         return dh, dWm, dWs, db, dgamma, dbeta, None, None, None
 
 
