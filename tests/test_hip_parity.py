@@ -699,6 +699,36 @@ def test_model_backward_matches_autograd_of_the_oracle(name, N, E, R, kind):
         assert_close(model(x.detach(), torch.from_numpy(ei).to(DEV), texts).cpu().numpy(), out.detach().cpu().numpy(), "eval")
 
 
+def test_training_side_streams_change_no_bit(monkeypatch):
+    """Large graphs train with the generators on a side stream (their backward then runs beside the message layers' gradient
+    kernels) and the layers' weight gradients beside the two gradient passes (autograd.py).  Forced on for a small graph, three
+    steps: output and every gradient bit for bit what the single-stream schedule computes."""
+    from graph_hypernetwork_forge_amd import autograd as A
+    cfg = cases.MODELS["c3"]
+    g = synth.make_kg(1500, 16000, 9, cfg.node_feat_dim, seed=77, kind="powerlaw")
+    ei, texts = torch.from_numpy(g.edge_index).to(DEV), g.edge_texts()
+    gout = torch.from_numpy(synth.normal(32, "gout", (1500, cfg.hidden_dim))).to(DEV)
+
+    def run(side: bool):
+        monkeypatch.setattr(HyperGNN, "SIDE_STREAM_MIN_EDGES", 0 if side else 1 << 60)
+        monkeypatch.setattr(A, "_EO_SIDE", side)
+        model = make_model(cfg, cfg.params()).train()
+        x = torch.from_numpy(g.node_features).to(DEV).requires_grad_(True)
+        for _ in range(3):                                             # (the streams are reused from the second step on)
+            model.zero_grad(set_to_none=True)
+            x.grad = None
+            out = model(x, ei, texts)
+            (out * gout).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach(), x.grad, {k: p.grad for k, p in model.named_parameters()}
+
+    out0, xg0, g0 = run(False)
+    out1, xg1, g1 = run(True)
+    assert torch.equal(out0, out1) and torch.equal(xg0, xg1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
 def test_training_mode_dropout_matches_reference_and_its_gradients(golden_dir, monkeypatch):
     """train() with dropout 0.25 (reference hypergnn.py:293-294, weight_generator.py:96-107): with the masks the reference drew
     (tests/golden/g_dropout.npz) handed to the HIP path in place of its own draws, the forward equals the reference's
