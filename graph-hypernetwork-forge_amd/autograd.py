@@ -283,9 +283,15 @@ class InputProjFn(torch.autograd.Function):
     """h0 = relu(x W^T + b) (reference hypergnn.py:261)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, tp=None):
+        """tp (a TrainPlan on a two-piece layout): the rows also leave cut into pieces for the first layer's gathers, by
+        the same launch, through the plan's carry."""
         x = x.contiguous().float()
-        h0 = _native.input_proj_fwd(x, W.detach(), b.detach())
+        split = tp is not None and tp.fwd.wlayout in _native.SPLIT_LAYOUTS and tp.fwd.block_nodes > 1
+        hs = _native.alloc_split(x.size(0), W.size(0), tp.fwd.wlayout, x.device) if split else None
+        h0 = _native.input_proj_fwd(x, W.detach(), b.detach(), h_split=hs, split_layout=tp.fwd.wlayout if split else 0)
+        if split:
+            tp.carry.put(h0, hs)
         ctx.save_for_backward(x, W, h0)
         return h0
 
@@ -300,7 +306,7 @@ class InputProjFn(torch.autograd.Function):
             if x.size(0) > 16 * 65535:
                 raise NotImplementedError("gradient with respect to node_features: at most 1,048,560 rows for now")
             dx = _native.matmul_nn(dz, W.detach().contiguous())
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class TextEncoderFn(torch.autograd.Function):

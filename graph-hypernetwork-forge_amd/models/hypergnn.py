@@ -282,7 +282,7 @@ class HyperGNN(nn.Module):
             for ws in generated:
                 for t in ws:
                     t.record_stream(main)
-        h = InputProjFn.apply(node_features, self.input_proj.weight, self.input_proj.bias)
+        h = InputProjFn.apply(node_features, self.input_proj.weight, self.input_proj.bias, plan.train)
         for l, (gen, norm) in enumerate(zip(self.weight_generators, self.layer_norms)):
             if side:
                 W_msg, W_self, bias = generated[l]
