@@ -146,6 +146,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_CR
 #define GHF_BX_CR 76         // rows per chunk
 #endif
+#ifndef GHF_BX_TLOADS
+#define GHF_BX_TLOADS 1      // 1: the tail's loads of a batch all issued before their first use (see tail_half); measured the same as 0
+#endif
 #ifndef GHF_BX_TGB
 #define GHF_BX_TGB 3         // tail: four-row groups in flight per wave (six per half at d = 128); measured 1: 3.21, 2: 3.23, 3: 3.18, 4: 3.27 ms
 #endif
@@ -332,18 +335,26 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         for (int g0 = w; g0 < NG; g0 += NWV * GB) {
             f32x4 x[GB][NV];
             float inv[GB];
+            int deg[GB];
+            // every load of the batch first, their uses behind a scheduling barrier: hipcc otherwise turns each in-degree into
+            // its reciprocal at once — a wait for that load and, the counter being in order, for every row load before it:
+            // three latencies per batch instead of one
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
                 const int g = g0 + gb * NWV;
                 const int nl = node_of(4 * (g < NG ? g : NG - 1) + sub);
                 const int64_t node = node0 + (nl < nrows ? nl : nrows - 1);
-                const int deg = indeg[node];
-                inv[gb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
+                deg[gb] = indeg[node];
                 const float* __restrict__ hp = h + (size_t)node * D + c0;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)              // (GHF_FLAG_ADD_H: the residual operand also without the tail)
                     x[gb][i] = (no_tail && !(no_tail & GHF_FLAG_ADD_H)) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4 * i);
             }
+#if GHF_BX_TLOADS
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int gb = 0; gb < GB; ++gb) inv[gb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg[gb] > 1 ? deg[gb] : 1);
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
                 const int g = g0 + gb * NWV;
