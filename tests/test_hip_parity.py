@@ -95,6 +95,13 @@ def test_score_triple_and_fused_edge_scores():
     assert_close(model.score_triple(embs[src], embs[dst]).cpu().numpy(), ref.numpy(), "score_triple [B, d]", atol=1e-4)
     one = model.score_triple(embs[3], embs[7])
     assert one.dim() == 0 and abs(one.item() - float(O.score_triple(embs[3].cpu(), embs[7].cpu()))) < 1e-4
+    # recorded: score_edges is the reference's call form, gradient included (float64 autograd of the oracle's score)
+    w = torch.from_numpy(synth.normal(9, "w", (E,))).to(DEV)
+    eg = embs.clone().requires_grad_(True)
+    (model.score_edges(eg, src, dst) * w).sum().backward()
+    e64 = embs.cpu().double().requires_grad_(True)
+    (O.score_triple(e64[src.cpu()], e64[dst.cpu()]) * w.cpu().double()).sum().backward()
+    assert_close(eg.grad.cpu().numpy(), e64.grad.float().numpy(), "d score_edges / d embs", atol=1e-4)
     # odd widths take the scalar path; an out-of-range index gives NaN, not a fault
     e20 = torch.from_numpy(synth.normal(9, "e20", (64, 20))).to(DEV)
     assert_close(_native.score_pairs_fwd(e20, e20).cpu().numpy(), (e20.cpu() ** 2).sum(-1).numpy(), "d = 20", atol=1e-5)
