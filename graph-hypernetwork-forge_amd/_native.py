@@ -58,6 +58,7 @@ SIGNATURES = {
     "ghf_group_workspace_bytes": (_sz, [_i64]),
     "ghf_group_edges": (_i32, [_vp, _i64, _i32, _vp, _sz, _vp, _vp, _vp]),
     "ghf_tail_bwd_workspace_floats": (_sz, [_i64, _i32]),
+    "ghf_segment_axpy": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "ghf_tail_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_colsum_workspace_floats": (_sz, [_i64, _i32]),
     "ghf_colsum": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
@@ -641,6 +642,18 @@ def rowscale(X: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
         raise ValueError("rowscale: one factor per row expected")
     out = torch.empty_like(X)
     _check(load().ghf_rowscale(_ptr(X), _ptr(g), n, d, _ptr(out), _stream()), "ghf_rowscale")
+    return out
+
+
+def segment_axpy(w: torch.Tensor, iw: torch.Tensor, X: torch.Tensor, ix: torch.Tensor, off: torch.Tensor) -> torch.Tensor:
+    """out[v] = sum_{e in off[v]..off[v+1]} w[iw[e]] * X[ix[e]] (include/ghf.h: ghf_segment_axpy)."""
+    w, X = _req(w, torch.float32, "w"), _req(X, torch.float32, "X")
+    iw, ix, off = _req(iw, torch.int64, "iw"), _req(ix, torch.int64, "ix"), _req(off, torch.int64, "off")
+    if iw.numel() != ix.numel():
+        raise ValueError("segment_axpy: one weight index per row index expected")
+    nseg, (nx, d) = off.numel() - 1, X.shape
+    out = torch.empty(nseg, d, dtype=torch.float32, device=X.device)
+    _check(load().ghf_segment_axpy(_ptr(w), _ptr(iw), _ptr(X), _ptr(ix), _ptr(off), nseg, nx, d, _ptr(out), _stream()), "ghf_segment_axpy")
     return out
 
 

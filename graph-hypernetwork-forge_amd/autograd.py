@@ -20,8 +20,8 @@ gathers; kernels without that side output run GHF_FLAG_NO_TAIL plus ``ghf_tail_f
 
 The callers either side of the layer have their own Functions here: ``WeightGeneratorFn`` (three MLP heads and the
 learnable log-scales, reference weight_generator.py:120-143), ``InputProjFn`` (hypergnn.py:261), ``TextEncoderFn``
-(hypergnn.py:57-81) and ``ScorePairsFn`` (hypergnn.py:304-318).  All of their contractions are ``A^T B`` over rows,
-i.e. ``ghf_group_outer`` again (``_native.matmul_tn``).
+(hypergnn.py:57-81), ``ScorePairsFn`` (hypergnn.py:304-318) and its fused form over index arrays ``ScoreEdgesFn``.  All of
+their contractions are ``A^T B`` over rows, i.e. ``ghf_group_outer`` again (``_native.matmul_tn``).
 """
 
 from __future__ import annotations
@@ -323,6 +323,29 @@ class TextEncoderFn(torch.autograd.Function):
         E, W, te, ids, lens = ctx.saved_tensors
         dE, dW, db = _native.text_encode_bwd(ids, lens, E.detach(), W.detach(), te, g.contiguous().float())
         return dE, dW, db, None, None
+
+
+class ScoreEdgesFn(torch.autograd.Function):
+    """s_i = embs[src_i] . embs[dst_i] without the two gathered [P, d] matrices (HyperGNN.score_edges).  Backward: the 2P
+    (node, partner, pair) entries grouped by node (ghf_group_edges, stable) and summed per node in that order —
+    d embs[v] = sum_{i: src_i = v} g_i embs[dst_i] + sum_{i: dst_i = v} g_i embs[src_i] — one gather pass, reproducible."""
+
+    @staticmethod
+    def forward(ctx, embs, src, dst):
+        embs = embs.contiguous().float()
+        src, dst = src.to(torch.int64).contiguous(), dst.to(torch.int64).contiguous()
+        ctx.save_for_backward(embs, src, dst)
+        return _native.score_pairs_fwd(embs, embs, src, dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        embs, src, dst = ctx.saved_tensors
+        P, N = src.numel(), embs.size(0)
+        keys = torch.cat([src, dst]).clamp_(0, N - 1)
+        perm, off = _native.group_edges(keys, N)
+        partner = torch.cat([dst, src]).index_select(0, perm)
+        pair = torch.remainder(perm, P)
+        return _native.segment_axpy(g.contiguous().float(), pair, embs, partner, off), None, None
 
 
 class ScorePairsFn(torch.autograd.Function):

@@ -955,6 +955,59 @@ int launch_rowscale(const float* X, const float* g, int64_t n, int d, float* out
     return GHF_OK;
 }
 
+// out[v][:] = sum_{e in off[v] .. off[v+1]} w[iw[e]] * X[ix[e]][:], e ascending (fixed order); empty segments give zeros.  One
+// wave per segment, VW adjacent columns per lane and 64 * VW columns per pass, two entries' rows in flight.  (The gradient of
+// fused edge scores: per node, the pairs it takes part in.)
+template <int VW>
+__global__ __launch_bounds__(256) void segment_axpy_kernel(const float* __restrict__ w, const int64_t* __restrict__ iw,
+                                                           const float* __restrict__ X, const int64_t* __restrict__ ix,
+                                                           const int64_t* __restrict__ off, int64_t nseg, int64_t nx, int d,
+                                                           float* __restrict__ out) {
+    typedef float vec __attribute__((ext_vector_type(VW)));
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= nseg) return;
+    const int64_t e0 = off[v], e1 = off[v + 1];
+    for (int c = VW * lane; c < d; c += 64 * VW) {
+        vec acc;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) acc[k] = 0.f;
+        auto row = [&](int64_t e) -> const vec* {
+            int64_t r = ix[e];
+            r = r < 0 ? 0 : (r >= nx ? nx - 1 : r);       // (ids are the caller's: clamped, never a fault)
+            return (const vec*)(X + (size_t)r * d + c);
+        };
+        int64_t e = e0;
+        for (; e + 2 <= e1; e += 2) {
+            const float w0 = w[iw[e]], w1 = w[iw[e + 1]];
+            const vec x0 = *row(e), x1 = *row(e + 1);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) acc[k] = fmaf(w1, x1[k], fmaf(w0, x0[k], acc[k]));
+        }
+        if (e < e1) {
+            const float w0 = w[iw[e]];
+            const vec x0 = *row(e);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) acc[k] = fmaf(w0, x0[k], acc[k]);
+        }
+        *(vec*)(out + (size_t)v * d + c) = acc;
+    }
+}
+
+int launch_segment_axpy(const float* w, const int64_t* iw, const float* X, const int64_t* ix, const int64_t* off, int64_t nseg,
+                        int64_t nx, int d, float* out, hipStream_t stream) {
+    GHF_REQUIRE(d > 0 && nx > 0, "segment_axpy: bad shape");
+    if (nseg <= 0) return GHF_OK;
+    GHF_REQUIRE(cdiv(nseg, 4) < (1ll << 31), "segment_axpy: too many segments per launch");
+    const unsigned grid = (unsigned)cdiv(nseg, 4);
+    const bool a16 = ((((uintptr_t)X | (uintptr_t)out) & 15) == 0);
+    if (a16 && d % 4 == 0 && d >= 256) segment_axpy_kernel<4><<<grid, 256, 0, stream>>>(w, iw, X, ix, off, nseg, nx, d, out);
+    else if (a16 && d % 2 == 0 && d >= 128) segment_axpy_kernel<2><<<grid, 256, 0, stream>>>(w, iw, X, ix, off, nseg, nx, d, out);
+    else segment_axpy_kernel<1><<<grid, 256, 0, stream>>>(w, iw, X, ix, off, nseg, nx, d, out);
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 int launch_transpose_batched(const float* in, int batch, int rows, int cols, float* out, hipStream_t stream) {
     GHF_REQUIRE(batch > 0 && rows > 0 && cols > 0 && batch < 65536, "transpose: bad shape");
     transpose_batched_kernel<<<dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32), (unsigned)batch), 256, 0, stream>>>(in, rows, cols, out);

@@ -295,6 +295,12 @@ int ghf_rowscale(const float* X, const float* g, int64_t n, int d, float* out, v
     return n > 0 ? launch_rowscale(X, g, n, d, out, (hipStream_t)stream) : GHF_OK;
 }
 
+int ghf_segment_axpy(const float* w, const int64_t* iw, const float* X, const int64_t* ix, const int64_t* off, int64_t nseg,
+                     int64_t nx, int d, float* out, void* stream) {
+    GHF_REQUIRE((w && iw && X && ix && off && out) || nseg == 0, "segment_axpy: null pointer argument");
+    return launch_segment_axpy(w, iw, X, ix, off, nseg, nx, d, out, (hipStream_t)stream);
+}
+
 int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, void* stream) {
     GHF_REQUIRE(X && Y && workspace && out, "dot: null pointer argument");
     return launch_dot(X, Y, n, workspace, out, (hipStream_t)stream);

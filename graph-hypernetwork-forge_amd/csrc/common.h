@@ -180,6 +180,8 @@ int launch_group_outer(const float* A, const int64_t* ia, int da, const float* B
                        const int64_t* gstart, const int64_t* gend, int ngroups, float* C, int accumulate, hipStream_t stream);
 int launch_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, hipStream_t stream);
 int launch_add3(const float* a, const float* b, const float* c, int64_t n, float* out, hipStream_t stream);
+int launch_segment_axpy(const float* w, const int64_t* iw, const float* X, const int64_t* ix, const int64_t* off, int64_t nseg,
+                        int64_t nx, int d, float* out, hipStream_t stream);
 int launch_rowscale(const float* X, const float* g, int64_t n, int d, float* out, hipStream_t stream);
 int edge_outer_supported(int d);
 int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,

@@ -475,11 +475,13 @@ class HyperGNN(nn.Module):
 
     def score_edges(self, embs: torch.Tensor, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
         """``score_triple(embs[src], embs[dst])`` (the reference's call form, demo.py:90-94) without materialising the
-        two gathered ``[E, d]`` matrices (when gradients are recorded it is that call itself)."""
+        two gathered ``[E, d]`` matrices — nor, when gradients are recorded, their index backward: the gradient is one
+        gather pass over the pairs grouped by node (``autograd.ScoreEdgesFn``), reproducible."""
         if not embs.is_cuda:
             raise RuntimeError(f"score_edges computes on an MI355X HIP device only (input is on {embs.device})")
-        if torch.is_grad_enabled() and embs.requires_grad:       # recorded: the reference's form (the gathers are torch's, with their backward)
-            return self.score_triple(embs[src], embs[dst])
+        if torch.is_grad_enabled() and embs.requires_grad:
+            from ..autograd import ScoreEdgesFn
+            return ScoreEdgesFn.apply(embs, src, dst)
         return _native.score_pairs_fwd(embs, embs, src.to(torch.int64), dst.to(torch.int64))
 
     def num_parameters(self) -> int:

@@ -289,6 +289,11 @@ int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int
 int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream);
 int ghf_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);
 int ghf_rowscale(const float* X, const float* g, int64_t n, int d, float* out, void* stream);
+/* out[v][:] = sum_{e = off[v] .. off[v+1]-1} w[iw[e]] * X[ix[e]][:]  (out [nseg,d], X [nx,d], off [nseg+1]; e ascending: fixed
+ * order; ix clamped into [0, nx)).  The gradient of the fused edge scores (ghf_score_pairs_fwd with index arrays): per node, the
+ * pairs it takes part in (grouped by ghf_group_edges with the node ids as keys). */
+int ghf_segment_axpy(const float* w, const int64_t* iw, const float* X, const int64_t* ix, const int64_t* off, int64_t nseg,
+                     int64_t nx, int d, float* out, void* stream);
 /* out[0] = sum_i X[i] Y[i] (fixed order); workspace: (n + 8191) / 8192 floats */
 int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, void* stream);
 /* Hidden activations of the weight generator's three heads (what its backward needs besides the outputs):

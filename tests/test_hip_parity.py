@@ -95,13 +95,25 @@ def test_score_triple_and_fused_edge_scores():
     assert_close(model.score_triple(embs[src], embs[dst]).cpu().numpy(), ref.numpy(), "score_triple [B, d]", atol=1e-4)
     one = model.score_triple(embs[3], embs[7])
     assert one.dim() == 0 and abs(one.item() - float(O.score_triple(embs[3].cpu(), embs[7].cpu()))) < 1e-4
-    # recorded: score_edges is the reference's call form, gradient included (float64 autograd of the oracle's score)
+    # recorded: score_edges with its own backward (autograd.ScoreEdgesFn: the pairs grouped by node, one gather pass) against
+    # float64 autograd of the oracle's score in the reference's call form; self pairs and repeated pairs included; twice the same bits
     w = torch.from_numpy(synth.normal(9, "w", (E,))).to(DEV)
-    eg = embs.clone().requires_grad_(True)
-    (model.score_edges(eg, src, dst) * w).sum().backward()
+    src2, dst2 = src % (N - 50), dst % (N - 50)                        # (the last 50 nodes are in no pair)
+    src2[:100] = dst2[:100]                                            # i -> i
+    src2[100:200], dst2[100:200] = src2[200:300], dst2[200:300]        # the same pair again
+    grads = []
+    for _ in range(2):
+        eg = embs.clone().requires_grad_(True)
+        s = model.score_edges(eg, src2, dst2)
+        (s * w).sum().backward()
+        grads.append(eg.grad)
     e64 = embs.cpu().double().requires_grad_(True)
-    (O.score_triple(e64[src.cpu()], e64[dst.cpu()]) * w.cpu().double()).sum().backward()
-    assert_close(eg.grad.cpu().numpy(), e64.grad.float().numpy(), "d score_edges / d embs", atol=1e-4)
+    s64 = O.score_triple(e64[src2.cpu()], e64[dst2.cpu()])
+    (s64 * w.cpu().double()).sum().backward()
+    assert_close(s.detach().cpu().numpy(), s64.detach().float().numpy(), "score_edges (recorded)", atol=1e-4)
+    assert_close(grads[0].cpu().numpy(), e64.grad.float().numpy(), "d score_edges / d embs", atol=1e-4)
+    assert torch.equal(grads[0], grads[1])
+    assert float(grads[0][N - 50:].abs().max()) == 0.0 and float(grads[0][:N - 50].abs().max()) > 0.0   # nodes in no pair: zeros
     # odd widths take the scalar path; an out-of-range index gives NaN, not a fault
     e20 = torch.from_numpy(synth.normal(9, "e20", (64, 20))).to(DEV)
     assert_close(_native.score_pairs_fwd(e20, e20).cpu().numpy(), (e20.cpu() ** 2).sum(-1).numpy(), "d = 20", atol=1e-5)

@@ -34,4 +34,5 @@ python3 bench.py > gpurun_out/r02/r02_bench_c3.json 2> gpurun_out/r02/bench_c3.e
 python3 bench.py --workload c2 --no-cpu-baseline --steps 50 --warmup 5 > gpurun_out/r02/r02_bench_c2.json 2> gpurun_out/r02/bench_c2.err
 python3 bench.py --workload c5 --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/r02/r02_bench_c5.json 2> gpurun_out/r02/bench_c5.err
 python3 tools/train_bench.py --steps 5 | tail -1 > gpurun_out/r02/r02_train_c3.json
+python3 tools/train_bench.py --steps 5 --score edges | tail -1 > gpurun_out/r02/r02_train_c3_score_edges.json
 ls -la gpurun_out/r02

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kind", default="uniform", choices=["uniform", "powerlaw"])
+    ap.add_argument("--score", default="triple", choices=["triple", "edges"],
+                    help="the loss's scores: score_triple(embs[src], embs[dst]) as in the reference's demo, or the fused score_edges")
     args = ap.parse_args()
     from graph_hypernetwork_forge_amd import HyperGNN, _native, synth
     _native.load()
@@ -52,8 +54,12 @@ def main():
             torch.cuda.synchronize()                      # the previous step's backward is still running otherwise
         t0 = time.perf_counter()
         embs = model.forward_ids(x, edge_index, rel, names)
-        pos = model.score_triple(embs[src], embs[dst])
-        neg = model.score_triple(embs[src], embs[dst[perm]])
+        if args.score == "edges":                       # the fused form (HyperGNN.score_edges); "triple": the reference's, demo.py:90-94
+            pos = model.score_edges(embs, src, dst)
+            neg = model.score_edges(embs, src, dst[perm])
+        else:
+            pos = model.score_triple(embs[src], embs[dst])
+            neg = model.score_triple(embs[src], embs[dst[perm]])
         loss = torch.clamp(1.0 - pos + neg, min=0.0).mean()
         if split is not None:
             torch.cuda.synchronize()
@@ -74,7 +80,7 @@ def main():
         step(fwd)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print(json.dumps({"workload": cfg["desc"], "kind": args.kind, "ms_per_train_step": ms, "forward_ms": 1e3 * sum(fwd) / len(fwd),
+    print(json.dumps({"workload": cfg["desc"], "kind": args.kind, "score": args.score, "ms_per_train_step": ms, "forward_ms": 1e3 * sum(fwd) / len(fwd),
                       "backward_ms": ms - 1e3 * sum(fwd) / len(fwd), "edges_per_s_train": E / (ms * 1e-3),
                       "cold_step_s": cold, "loss": float(loss), "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9}))
 
