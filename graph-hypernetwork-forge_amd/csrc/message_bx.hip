@@ -149,6 +149,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_TLOADS
 #define GHF_BX_TLOADS 1      // 1: the tail's loads of a batch all issued before their first use (see tail_half); measured the same as 0
 #endif
+#ifndef GHF_BX_TCOL
+#define GHF_BX_TCOL 1        // 1: the tail's lanes take columns 4l + 64i (see tail_half): 3.16 -> 3.13 ms; the training forward's launch (one more store) -0.15 ms
+#endif
 #ifndef GHF_BX_TGB
 #define GHF_BX_TGB 3         // tail: four-row groups in flight per wave (six per half at d = 128); measured 1: 3.21, 2: 3.23, 3: 3.18, 4: 3.27 ms
 #endif
@@ -297,7 +300,16 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     auto tail_half = [&](int half, auto gb_c) __attribute__((always_inline)) {          // gb_c: four-row groups in flight per wave
         if (GHF_BXEXP & 32) return;
         const float* acc_lds = (const float*)smem;       // dump rows, natural column order
+#if GHF_BX_TCOL
+        // a lane's CPL columns: 4 (lane mod 16) + 64 i + (0..3), i < NV — every 16-byte load / store of a row's 16 lanes is one
+        // contiguous 256 bytes (whole 128-byte lines per instruction); adjacent columns per lane left half of each line to the
+        // lane's next instruction
+        constexpr int CS = 64;
+        const int sub = lane >> 4, c0 = 4 * (lane & 15);
+#else
+        constexpr int CS = 4;
         const int sub = lane >> 4, c0 = CPL * (lane & 15);
+#endif
         constexpr int NV = CPL / 4;                      // 16-byte pieces per lane and row
         auto node_of = [&](int v) -> int { return (v / HPW) * NPW + half * HPW + (v % HPW); };   // block-local node of dump row v
         auto row_sum = [&](float v) -> float {           // over the 16 lanes of a row, result in each of them
@@ -321,15 +333,15 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 const int v = 4 * g + sub;
                 float* __restrict__ o = ps + (size_t)node_of(v) * D + c0;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) *(f32x4*)(o + 4 * i) = *(const f32x4*)(acc_lds + v * D + c0 + 4 * i);
+                for (int i = 0; i < NV; ++i) *(f32x4*)(o + CS * i) = *(const f32x4*)(acc_lds + v * D + c0 + CS * i);
             }
             return;
         }
         float gm[CPL], bt[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            gm[c] = no_tail ? 1.f : gamma[c0 + c];
-            bt[c] = no_tail ? 0.f : beta[c0 + c];
+            gm[c] = no_tail ? 1.f : gamma[c0 + CS * (c >> 2) + (c & 3)];
+            bt[c] = no_tail ? 0.f : beta[c0 + CS * (c >> 2) + (c & 3)];
         }
         constexpr int GB = decltype(gb_c)::value;
         for (int g0 = w; g0 < NG; g0 += NWV * GB) {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 const float* __restrict__ hp = h + (size_t)node * D + c0;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)              // (GHF_FLAG_ADD_H: the residual operand also without the tail)
-                    x[gb][i] = (no_tail && !(no_tail & GHF_FLAG_ADD_H)) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + 4 * i);
+                    x[gb][i] = (no_tail && !(no_tail & GHF_FLAG_ADD_H)) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + CS * i);
             }
 #if GHF_BX_TLOADS
             __builtin_amdgcn_sched_barrier(0);
@@ -363,11 +375,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 const bool live = g < NG && nl < nrows;
                 f32x4 a[NV];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) a[i] = *(const f32x4*)(acc_lds + v * D + c0 + 4 * i);
+                for (int i = 0; i < NV; ++i) a[i] = *(const f32x4*)(acc_lds + v * D + c0 + CS * i);
                 if (agg_out && live) {                   // side output: the mean before the tail (what the backward keeps)
                     float* __restrict__ o = agg_out + (size_t)(node0 + nl) * D + c0;
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) *(f32x4*)(o + 4 * i) = a[i] * inv[gb];
+                    for (int i = 0; i < NV; ++i) *(f32x4*)(o + CS * i) = a[i] * inv[gb];
                 }
                 float y[CPL];
                 float s = 0.f;
@@ -398,15 +410,21 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 if (live) {
                     float* __restrict__ o = h_out + (size_t)(node0 + nl) * D + c0;
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) *(f32x4*)(o + 4 * i) = (f32x4){y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3]};
+                    for (int i = 0; i < NV; ++i) *(f32x4*)(o + CS * i) = (f32x4){y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3]};
                     if (h_split_out) {
                         _Float16* __restrict__ sp = (_Float16*)h_split_out + (size_t)(node0 + nl) * (NPL * D) + c0;
                         _Float16 hi[CPL], lo[CPL];
 #pragma unroll
                         for (int c = 0; c < CPL; ++c) split2h(y[c] * up, hi[c], lo[c]);
-                        if constexpr (CPL == 8) {
+                        if constexpr (CPL == 8 && CS == 4) {
                             *(f16x8*)sp = (f16x8){hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
                             *(f16x8*)(sp + D) = (f16x8){lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+                        } else if constexpr (CPL == 8) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                *(f16x4*)(sp + CS * i) = (f16x4){hi[4 * i], hi[4 * i + 1], hi[4 * i + 2], hi[4 * i + 3]};
+                                *(f16x4*)(sp + D + CS * i) = (f16x4){lo[4 * i], lo[4 * i + 1], lo[4 * i + 2], lo[4 * i + 3]};
+                            }
                         } else {
                             *(f16x4*)sp = (f16x4){hi[0], hi[1], hi[2], hi[3]};
                             *(f16x4*)(sp + D) = (f16x4){lo[0], lo[1], lo[2], lo[3]};
