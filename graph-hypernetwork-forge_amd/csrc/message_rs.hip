@@ -236,9 +236,12 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4) {
                             const int ct = 4 * ch + c4;
+                            // the product TRANSPOSED (the weights' fragment as the A operand): a lane then holds four
+                            // consecutive columns of ONE row — 16-byte stores of the results (one column of four rows:
+                            // 4-byte stores, four times the store instructions)
                             auto fma = [&](int pa, int pb) {
-                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt][pa]),
-                                                                                     __builtin_bit_cast(f16x8, b[c4][pb]), acc[rt][ct], 0, 0, 0);
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[c4][pb]),
+                                                                                     __builtin_bit_cast(f16x8, a[rt][pa]), acc[rt][ct], 0, 0, 0);
                             };
                             fma(1, 0); fma(0, 1);          // lo*hi, hi*lo
                             fma(0, 0);                     // hi*hi
@@ -261,32 +264,35 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
     };
     run_half(std::integral_constant<int, 0>{});
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)                         // from the source rows' scale to the destination rows' (exact)
+    for (int rt = 0; rt < 2; ++rt) {                       // from the source rows' scale to the destination rows' (exact)
+        const int row = 32 * w + 16 * rt + c16;
+        const float ratio = rsc[0][row] / rsc[1][row];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int row = 32 * w + 16 * rt + 4 * q + s;
-            const float ratio = rsc[0][row] / rsc[1][row];
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) acc[rt][ct][s] *= ratio;
-        }
+        for (int ct = 0; ct < 8; ++ct) acc[rt][ct] *= ratio;
+    }
     run_half(std::integral_constant<int, 1>{});
-    // D: lane holds rows 4q + s, column c16 of a tile
-    float bv[8];
+    // D (transposed product): lane holds row c16 of a row tile, columns 4q + s of a column tile
+    f32x4 bv[8];
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) bv[ct] = bias[(size_t)r * d + n0 + 16 * ct + c16];
+    for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int s = 0; s < 4; ++s) bv[ct][s] = bias[(size_t)r * d + n0 + 16 * ct + 4 * q + s];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int row = 32 * w + 16 * rt + 4 * q + s;
-            const int64_t ee = e0 + row;
-            if (ee < e1) {
-                const float fv = rsc[1][row] * wscale, n = rsc[2][row];
-                float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + c16;
+    for (int rt = 0; rt < 2; ++rt) {
+        const int row = 32 * w + 16 * rt + c16;
+        const int64_t ee = e0 + row;
+        if (ee < e1) {
+            const float fv = rsc[1][row] * wscale, n = rsc[2][row];
+            float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + 4 * q;
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct) y[16 * ct] = fmaf(acc[rt][ct][s], fv, bv[ct] * n);
+            for (int ct = 0; ct < 8; ++ct) {
+                f32x4 o;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) o[s] = fmaf(acc[rt][ct][s], fv, bv[ct][s] * n);
+                *(f32x4*)(y + 16 * ct) = o;
             }
         }
+    }
 }
 
 // ghf_weights_pack_rs: natural W_msg, W_self [R][d][d] -> w2h (see above).  One workgroup per relation finds the
