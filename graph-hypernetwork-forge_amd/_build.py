@@ -46,6 +46,8 @@ for _k in ("U", "CR"):                                  # message_bx.hip, hidden
 _i = _re.search(r"ipexp(\d+)", VARIANT)
 if _i:
     FLAGS.append("-DGHF_IPEXP=" + _i.group(1))          # input_proj.hip timing experiments
+if "eopin" in VARIANT:
+    FLAGS.append("-DGHF_EO_PIN")
 if "eoslow" in VARIANT:
     FLAGS.append("-DGHF_EO_SLOW_FRAG")                  # debug: edge_outer_h fragments read element by element
 _m = _re.search(r"(?<!bx)exp(\d+)", VARIANT)

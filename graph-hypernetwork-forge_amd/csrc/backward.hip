@@ -608,29 +608,38 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
 #pragma unroll
     for (int j = 0; j < LPR; ++j) bsum[j] = zero4;
 
-    int64_t is[LPR], iv[LPR], id[LPR];                    // indices of the tile to gather next
-    f32x4 st[3][LPR];                                     // its rows on their way to LDS
-    auto load_idx = [&](int tile) {
+    // The indices of a tile are loaded a whole step before its rows (two sets), and every load is unconditional (rows past the
+    // slice's end read its last edge's and are zeroed afterwards): straight-line code, so the compiler's counted waits name
+    // exactly the loads they need.  (With `ok ? load : 0` branches each group of loads sat in its own basic block behind an
+    // s_waitcnt vmcnt(0): three dependent HBM round trips per tile.)
+    struct Idx { int s[LPR], v[LPR], d[LPR]; bool ok[LPR]; };           // (node ids fit 31 bits: the plan's limit)
+    Idx ix0, ix1;
+    // Rows on their way to LDS: TWO tiles in flight (two register sets).  With one, a tile's rows had one tile's MFMAs (~0.7 us)
+    // to arrive — less than an HBM round trip — and the workgroup waited for them every iteration: 48 KB in flight per CU,
+    // 4.7 TB/s over the chip, the latency-bound rate.
+    struct Stage { f32x4 r[3][LPR]; };
+    Stage st0, st1;
+    auto load_idx = [&](int tile, Idx& I) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
             const int64_t e = e0 + (int64_t)tile * EO_ET + (t + NT * j) / F4;
-            const bool ok = e < e1;
-            is[j] = ok ? ia[e] : -1;
-            iv[j] = ok ? ib[e] : -1;
-            id[j] = ok ? dst[e] : -1;
+            I.ok[j] = e < e1;
+            const int64_t ec = I.ok[j] ? e : e1 - 1;      // (e1 > e0: a slice is never empty)
+            I.s[j] = (int)ia[ec];
+            I.v[j] = (int)ib[ec];
+            I.d[j] = (int)dst[ec];
         }
     };
-    auto gather = [&]() {
+    auto gather = [&](Stage& S, const Idx& I) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
             const int c4 = (t + NT * j) % F4;
-            const bool ok = is[j] >= 0;
-            st[0][j] = ok ? *(const f32x4*)(h + (size_t)is[j] * ld + xa_col + 4 * c4) : zero4;
-            st[1][j] = ok ? *(const f32x4*)(h + (size_t)iv[j] * ld + xb_col + 4 * c4) : zero4;
-            st[2][j] = ok ? *(const f32x4*)(G + (size_t)id[j] * ld + g_col + 4 * c4) : zero4;
+            S.r[0][j] = *(const f32x4*)(h + (size_t)I.s[j] * ld + xa_col + 4 * c4);
+            S.r[1][j] = *(const f32x4*)(h + (size_t)I.v[j] * ld + xb_col + 4 * c4);
+            S.r[2][j] = *(const f32x4*)(G + (size_t)I.d[j] * ld + g_col + 4 * c4);
         }
     };
-    auto commit = [&](int buf) {                          // cut into pieces, row-major images
+    auto commit = [&](int buf, const Stage& S, const Idx& I) {   // cut into pieces, row-major images (I: whose rows exist)
         char* base = eoh_lds + (size_t)buf * 6 * IMG;
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
@@ -643,14 +652,14 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     _Float16 hi, lo;
-                    split2h(st[reg][j][e] * up, hi, lo);
+                    split2h((I.ok[j] ? S.r[reg][j][e] : 0.f) * up, hi, lo);
                     hi4[e] = hi;
                     lo4[e] = lo;
                 }
                 *(eo_f16x4*)(base + (2 * reg) * IMG + o) = hi4;
                 *(eo_f16x4*)(base + (2 * reg + 1) * IMG + o) = lo4;
             }
-            bsum[j] += st[2][j];                          // db rides along: this thread's column quad, exact fp32
+            if (I.ok[j]) bsum[j] += S.r[2][j];            // db rides along: this thread's column quad, exact fp32
         }
     };
     // fragment of 16 columns (features fb .. fb+15) x 32 rows (edges) of an image: what lane (Q, c16) needs is column c16, rows
@@ -676,15 +685,27 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
         return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    load_idx(0);
-    gather();
-    load_idx(1);                                          // (past the slice: every lane reads nothing)
-    commit(0);
+    Idx ixc0, ixc1;                                       // (only .ok is read: whose rows of st0 / st1 exist)
+    load_idx(0, ix0);
+    gather(st0, ix0);
+    ixc0 = ix0;
+    load_idx(1, ix1);
+    load_idx(2, ix0);                                     // (before tile 1's rows: the loop is entered with its loads outstanding in
+    gather(st1, ix1);                                     //  the order an iteration leaves them — indices, then rows — or the compiler's
+    ixc1 = ix1;                                           //  merged wait at the loop header drains everything)
+    commit(0, st0, ixc0);
     __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        gather();                                         // tile + 1 (indices were loaded an iteration ago)
-        load_idx(tile + 2);
+    // one tile: its MFMAs on buffer `buf`; `sg` receives tile + 2's rows (indices `ig`, loaded a step ago; `in` receives tile +
+    // 3's, ahead of these row loads in the counter's order), `sc` holds tile + 1's
+    auto step = [&](int tile, int buf, Stage& sg, Idx& okg, const Stage& sc, const Idx& okc, const Idx& ig, Idx& in)
+                    __attribute__((always_inline)) {
+        load_idx(tile + 3, in);
+        gather(sg, ig);
+#pragma unroll
+        for (int j = 0; j < LPR; ++j) okg.ok[j] = ig.ok[j];
+#ifdef GHF_EO_PIN
+        __builtin_amdgcn_sched_barrier(0);                // (experiment: the loads pinned at the top of the step)
+#endif
         const char* base = eoh_lds + (size_t)buf * 6 * IMG;
         const char* ximg = base + (rg >> 1) * 2 * IMG;    // rows 0..127 of [X_src | X_dst] are the source image, 128..255 the destination one
         const char* gimg = base + 4 * IMG;
@@ -705,8 +726,12 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
                 acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[bi], acc[ai][bi], 0, 0, 0);
             }
         }
-        commit(buf ^ 1);
+        commit(buf ^ 1, sc, okc);
         __syncthreads();
+    };
+    for (int tile = 0; tile < ntiles; tile += 2) {
+        step(tile, 0, st0, ixc0, st1, ixc1, ix0, ix1);
+        if (tile + 1 < ntiles) step(tile + 1, 1, st1, ixc1, st0, ixc0, ix1, ix0);
     }
     // partial product: tile (ai, bi) register s is row rg*64 + 16 ai + 4Q + s, column cg*64 + 16 bi + c16
     const float down = pow2f(-sx) * pow2f(-sg);
