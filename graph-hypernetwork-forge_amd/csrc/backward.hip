@@ -422,26 +422,30 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
     float bsum = 0.f;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // (every load unconditional — rows past the slice's end read its last edge's and are zeroed on the way to LDS: branches
+    // around the loads put each group of them behind an s_waitcnt vmcnt(0), see edge_outer_h_kernel)
     int64_t is[LPR], iv[LPR], id[LPR];                    // indices of the tile to gather next
+    bool okn[LPR], okc[LPR];                              // ... which of its rows exist; the same for the rows in st
     f32x4 st[3][LPR];                                     // its rows on their way to LDS
     auto load_idx = [&](int tile) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
             const int64_t e = e0 + (int64_t)tile * EO_ET + (t + NT * j) / F4;
-            const bool ok = e < e1;
-            is[j] = ok ? ia[e] : -1;
-            iv[j] = ok ? ib[e] : -1;
-            id[j] = ok ? dst[e] : -1;
+            okn[j] = e < e1;
+            const int64_t ec = okn[j] ? e : e1 - 1;
+            is[j] = ia[ec];
+            iv[j] = ib[ec];
+            id[j] = dst[ec];
         }
     };
     auto gather = [&]() {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
             const int c4 = (t + NT * j) % F4;
-            const bool ok = is[j] >= 0;
-            st[0][j] = ok ? *(const f32x4*)(h + (size_t)is[j] * ld + xa_col + 4 * c4) : zero4;
-            st[1][j] = ok ? *(const f32x4*)(h + (size_t)iv[j] * ld + xb_col + 4 * c4) : zero4;
-            st[2][j] = ok ? *(const f32x4*)(G + (size_t)id[j] * ld + g_col + 4 * c4) : zero4;
+            okc[j] = okn[j];
+            st[0][j] = *(const f32x4*)(h + (size_t)is[j] * ld + xa_col + 4 * c4);
+            st[1][j] = *(const f32x4*)(h + (size_t)iv[j] * ld + xb_col + 4 * c4);
+            st[2][j] = *(const f32x4*)(G + (size_t)id[j] * ld + g_col + 4 * c4);
         }
     };
     auto commit = [&](int buf) {
@@ -449,9 +453,9 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
         for (int j = 0; j < LPR; ++j) {
             const int row = (t + NT * j) / F4, c4 = (t + NT * j) % F4;
             float* xr = Xt + ((size_t)buf * EO_ET + row) * 2 * D;
-            *(f32x4*)(xr + 4 * c4) = st[0][j];
-            *(f32x4*)(xr + D + 4 * c4) = st[1][j];
-            *(f32x4*)(Gt + ((size_t)buf * EO_ET + row) * D + 4 * c4) = st[2][j];
+            *(f32x4*)(xr + 4 * c4) = okc[j] ? st[0][j] : zero4;
+            *(f32x4*)(xr + D + 4 * c4) = okc[j] ? st[1][j] : zero4;
+            *(f32x4*)(Gt + ((size_t)buf * EO_ET + row) * D + 4 * c4) = okc[j] ? st[2][j] : zero4;
         }
     };
 
