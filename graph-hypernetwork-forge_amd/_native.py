@@ -165,7 +165,7 @@ def _req(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 
 # ---- range guard of the two-fp16-piece kernels (include/ghf.h: ghf_set_range_flag) -------------------------------
-RANGE_ROWS, RANGE_WEIGHTS = 1, 2
+RANGE_ROWS, RANGE_WEIGHTS, RANGE_WEAK_W = 1, 2, 4
 _range_flag: Optional[torch.Tensor] = None
 
 

@@ -102,6 +102,26 @@ __device__ __forceinline__ int range_tiny(float xs) { const float a = fabsf(xs);
 __device__ __forceinline__ void range_raise(int32_t* flag, int bit, int tiny, int nonzero) {
     if (flag && tiny > 0 && tiny * 8 >= nonzero) atomicOr(flag, bit);
 }
+// GHF_RANGE_WEAK_W (include/ghf.h): one relation's [2d, d] matrix has an input row k whose L1 norm s[k] is below
+// d 2^-16 of the largest row's — the case in which far-down entries of a row of h (or of the matrix) can carry the whole
+// result.  Without such a row both error terms of the two-piece product stay within 2^-22 sum |x_k w_k| (ghf.h).
+// A wave's rows: (smallest, largest) row norm of each half [W_msg; W_self]; a half that is zero throughout (the backward's
+// GHF_FLAG_ZERO_* passes) takes no part.
+struct WeakRows {
+    float mn[2], mx[2];
+    __device__ __forceinline__ void init() { mn[0] = mn[1] = 3.0e38f; mx[0] = mx[1] = 0.f; }
+    __device__ __forceinline__ void add(int half, float s) { mn[half] = fminf(mn[half], s); mx[half] = fmaxf(mx[half], s); }
+    __device__ __forceinline__ void merge(const WeakRows& o) {
+        for (int h = 0; h < 2; ++h) { mn[h] = fminf(mn[h], o.mn[h]); mx[h] = fmaxf(mx[h], o.mx[h]); }
+    }
+    __device__ __forceinline__ bool weak(int d) const {
+        const float top = fmaxf(mx[0], mx[1]), thr = top * ((float)d * (1.0f / 65536.0f));
+        return (mx[0] > 0.f && mn[0] < thr) || (mx[1] > 0.f && mn[1] < thr);
+    }
+};
+__device__ __forceinline__ void range_raise_weak(int32_t* flag, const WeakRows& w, int d) {
+    if (flag && w.weak(d)) atomicOr(flag, 4 /* GHF_RANGE_WEAK_W */);
+}
 
 // Sum over a block of NWAVES*64 threads; `red` is >= NWAVES floats of LDS.
 // All threads get the result.  Contains two barriers.

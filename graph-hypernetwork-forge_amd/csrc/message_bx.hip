@@ -506,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 if (!GHF_BX_LATE && RPP * rb >= rows) continue;
                 const int g = (lane & (LPR - 1)) ^ akey(row);
                 // dead rows: an offset past the end of the buffer (zeros, no memory access)
-                const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : 0x7FFFFF00;
+                const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : (int)0xFFFFF000u;
                 // a piece past the tile (RBN not a multiple of 4 waves) lands in a scratch KiB
                 const unsigned dst = rb < RBN ? tile_off + (unsigned)rb * 1024u : DUMMY_OFF;
 #pragma unroll
@@ -1103,9 +1103,11 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     const int64_t row_end = a.row0 + a.rows;
     GHF_REQUIRE(row_end == a.N || row_end % C::BN == 0, "message(bx): row range must end on a block boundary or at N");
     if (a.rows <= 0) return GHF_OK;
-    GHF_REQUIRE((uint64_t)a.N * (D * 4 + 4) < (1ull << 31) && (uint64_t)a.E * 4 < (1ull << 32) &&
+    // (dead rows point at byte 0xFFFFF000 of the row table's buffer: past its end — zeros, no memory access — while N*(4d+4)
+    // stays below that; plan.block_kernel_max_nodes routes larger graphs to a CSR plan)
+    GHF_REQUIRE((uint64_t)a.N * (D * 4 + 4) <= 0xFFFFF000ull && (uint64_t)a.E * 4 < (1ull << 32) &&
                     (uint64_t)a.R * (2 * D * D * 4 + 4) < (1ull << 32),
-                "message(bx): 32-bit byte offsets need N*(4d+4) below 2 GiB, E*4 and R*(8d*d+4) below 4 GiB");
+                "message(bx): 32-bit byte offsets need N*(4d+4) <= 4 GiB - 4 KiB, E*4 and R*(8d*d+4) below 4 GiB");
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(bx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(bx): split blocks need the `partial` scratch");
     const int skip = ((a.flags & GHF_FLAG_ZERO_SRC) ? 1 : 0) | ((a.flags & GHF_FLAG_ZERO_DST) ? 2 : 0);

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void message_hx_kernel(
             if ((dbg & 1) || (GHF_EXP & 16)) node = (uint32_t)node0;
             // no branch around the loads of a dead tile (see decode): they get an offset past the end of the buffer,
             // which the buffer's range check answers with zeros without touching memory
-            const int off = m < mts ? (int)(node * (uint32_t)HROW) + ((lane % GPR) << 4) : 0x7FFFFF00;
+            const int off = m < mts ? (int)(node * (uint32_t)HROW) + ((lane % GPR) << 4) : (int)0xFFFFF000u;
             if (GHF_EXP & 2) continue;
 #pragma unroll
             // source rows are read about once per CU from a 512 MB table: non-temporal, so that they do not push the
@@ -610,7 +610,7 @@ static int launch_hx_for(const MsgArgs& a, hipStream_t stream) {
     const int64_t row_end = a.row0 + a.rows;
     GHF_REQUIRE(row_end == a.N || row_end % C::BN == 0, "message(hx): row range must end on a block boundary or at N");
     if (a.rows <= 0) return GHF_OK;
-    GHF_REQUIRE((uint64_t)a.N * (D * 4 + 4) < (1ull << 32) && (uint64_t)a.E * 4 < (1ull << 32) &&
+    GHF_REQUIRE((uint64_t)a.N * (D * 4 + 4) <= 0xFFFFF000ull && (uint64_t)a.E * 4 < (1ull << 32) &&
                     (uint64_t)a.R * (2 * D * D * 4 + 4) < (1ull << 32),
                 "message(hx): 32-bit byte offsets need N*(4d+4), E*4 and R*(8d*d+4) below 4 GiB");
     static const int dbg = getenv("GHF_DEBUG_FLAGS") ? atoi(getenv("GHF_DEBUG_FLAGS")) : 0;   // honoured by -DGHF_ABLATE builds only

@@ -298,19 +298,31 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
 // ghf_weights_pack_rs: natural W_msg, W_self [R][d][d] -> w2h (see above).  One workgroup per relation finds the
 // largest magnitude of both matrices; a second kernel scales, cuts and transposes.
 __global__ __launch_bounds__(256) void rs_wmax_kernel(const float* __restrict__ Wm, const float* __restrict__ Ws, int d,
-                                                      float* __restrict__ inv_scale, int* __restrict__ shift) {
+                                                      float* __restrict__ inv_scale, int* __restrict__ shift,
+                                                      int32_t* __restrict__ range_flag) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
+    __shared__ WeakRows weak_red[4];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t n = (size_t)d * d;
+    // a wave per input row: the largest magnitude, and the rows' L1 norms for the weak-row guard (common.h: WeakRows)
     float mx = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, fmaxf(fabsf(Wm[r * n + i]), fabsf(Ws[r * n + i])));
+    WeakRows wr;
+    wr.init();
+    for (int row = wv; row < 2 * d; row += 4) {
+        const float* __restrict__ p = (row < d ? Wm : Ws) + r * n + (size_t)(row < d ? row : row - d) * d;
+        float s = 0.f;
+        for (int o = lane; o < d; o += 64) { const float a = fabsf(p[o]); s += a; mx = fmaxf(mx, a); }
+        wr.add(row >= d, wave_sum(s));
+    }
     mx = wave_absmax(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    if (lane == 0) { red[wv] = mx; weak_red[wv] = wr; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int sh = split2h_shift(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
         shift[r] = sh;
         inv_scale[r] = pow2f(-sh);
+        for (int i = 1; i < 4; ++i) wr.merge(weak_red[i]);
+        range_raise_weak(range_flag, wr, d);
     }
 }
 __global__ __launch_bounds__(256) void rs_wpack_kernel(const float* __restrict__ Wm, const float* __restrict__ Ws, int d,
@@ -561,7 +573,7 @@ size_t weights_rs_bytes(int R, int d) { return (size_t)R * 8 * d * d + (size_t)R
 int launch_weights_pack_rs(const float* Wm, const float* Ws, int R, int d, void* out, int* shift_ws, hipStream_t stream) {
     GHF_REQUIRE(message_rs_supported(d) && R > 0, "weights_pack_rs: d = %d is not a relation-stationary width", d);
     float* inv = (float*)((char*)out + (size_t)R * 8 * d * d);
-    rs_wmax_kernel<<<R, 256, 0, stream>>>(Wm, Ws, d, inv, shift_ws);
+    rs_wmax_kernel<<<R, 256, 0, stream>>>(Wm, Ws, d, inv, shift_ws, range_flag_ptr());
     GHF_LAUNCH_CHECK();
     rs_wpack_kernel<<<dim3(d / 32, d / 32, 2 * R), 256, 0, stream>>>(Wm, Ws, d, shift_ws, (_Float16*)out, range_flag_ptr());
     GHF_LAUNCH_CHECK();

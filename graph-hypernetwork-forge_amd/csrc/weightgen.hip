@@ -203,6 +203,7 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
     extern __shared__ float wbuf[];                      // [2d][d]
     __shared__ float red[16];
     __shared__ int cnt[2];
+    __shared__ WeakRows weak_red[16];
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     const int r = blockIdx.x, tid = threadIdx.x, n = 2 * d * d;
     float* __restrict__ mine = W + (size_t)r * n;
@@ -217,6 +218,18 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
     __syncthreads();                                     // also: every load of `mine` happened before any store below
     mx = 0.f;
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
+    {   // range guard, weak input rows (common.h: WeakRows): L1 norms of the 2d rows, a wave per row
+        WeakRows wr;
+    wr.init();
+        wr.init();
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int row = wv; row < 2 * d; row += 16) {
+            float s = 0.f;
+            for (int o = lane; o < d; o += 64) s += fabsf(wbuf[row * d + o]);
+            wr.add(row >= d, wave_sum(s));
+        }
+        if (lane == 0) weak_red[wv] = wr;
+    }
     const int sh = split2h_shift(mx);
     const float up = pow2f(sh);
     if (tid == 0) scales[r] = pow2f(-sh);
@@ -243,7 +256,12 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, 
         if (nz) atomicAdd(&cnt[1], nz);
     }
     __syncthreads();
-    if (tid == 0) range_raise(range_flag, GHF_RANGE_WEIGHTS, cnt[0], cnt[1]);
+    if (tid == 0) {
+        range_raise(range_flag, GHF_RANGE_WEIGHTS, cnt[0], cnt[1]);
+        WeakRows wr = weak_red[0];
+        for (int i = 1; i < 16; ++i) wr.merge(weak_red[i]);
+        range_raise_weak(range_flag, wr, d);
+    }
 }
 
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,

@@ -38,7 +38,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native
-from .plan import GraphPlan, PlanCache, build_plan, build_rs, plan_config, relation_ids
+from .plan import CSR_CONFIG, GraphPlan, PlanCache, block_kernel_max_nodes, build_plan, build_rs, plan_config, relation_ids
 
 
 @dataclass
@@ -123,10 +123,15 @@ def shard_spec(N: int, block_nodes: int, world: int, rank: int, chunks: int = 1,
 class NativeOps:
     """The product compute steps: C-ABI calls only."""
 
-    def message_config(self, d: int, E: int):
-        return plan_config(d, E)
+    def message_config(self, d: int, E: int, N: Optional[int] = None, exact: bool = False):
+        if exact:                                                   # the range guard's fallback (plan.build_plan(exact=True))
+            cfg = _native.exact_config(d)
+            return CSR_CONFIG if N is not None and cfg[0] > 1 and N > block_kernel_max_nodes(d, cfg[1]) else cfg
+        return plan_config(d, E, N)
 
-    def build_plan(self, edge_index, rel_ids, unique, N, d, device, **shard) -> GraphPlan:
+    def build_plan(self, edge_index, rel_ids, unique, N, d, device, exact: bool = False, **shard) -> GraphPlan:
+        if exact:
+            return build_plan(edge_index, rel_ids, unique, N, d, device, exact=True, **shard)
         return build_plan(edge_index, rel_ids, unique, N, d, device,
                           force_generic=_native.prefer_rs(d, len(unique)) and "edge_range" not in shard, **shard)
 
@@ -227,10 +232,11 @@ class ShardedHyperGNN:
         self._fused_gather = self.backend != "gloo"                      # all_gather_into_tensor / reduce_scatter_tensor
         self.profile = "full"                                            # "compute" / "exchange": bench.py's breakdown passes
         self.stats: Dict[str, float] = {}
-        self._plan_key = None
+        self._plans: Dict[Tuple, Tuple] = {}                             # key -> (plan, spec, 1/in-degree, inputs kept alive)
         self._plan = None
         self._spec: Optional[ShardSpec] = None
         self._inv = None
+        self.last_range_flags = 0                                        # what the range guard saw in the last forward (OR over ranks)
         self._comm_stream = None
         self._compute_streams: List = []
 
@@ -343,64 +349,87 @@ class ShardedHyperGNN:
             main.wait_stream(self._comm_stream)                # every row of `buf` is in place for the next layer
 
     # -- plan -------------------------------------------------------------------------------------------
-    def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], N: int, device) -> GraphPlan:
+    def plan_for(self, edge_index: torch.Tensor, edge_texts: Sequence[str], N: int, device, exact: bool = False) -> GraphPlan:
+        """This rank's plan (and, in self._spec / self._inv, its shard geometry).  exact: the same shards planned for the exact
+        fp32 kernels — what every rank reruns on when the range guard fired on any of them."""
         key = PlanCache.key(edge_index, edge_texts, N, self.model.hidden_dim, device,
-                            extra=(self.world, self.rank, self.chunks, self.mode, self.balance))
-        if key != self._plan_key or os.environ.get("GHF_PLAN_CACHE") == "0":
+                            extra=(self.world, self.rank, self.chunks, self.mode, self.balance, bool(exact)))
+        hit = None if os.environ.get("GHF_PLAN_CACHE") == "0" else self._plans.get(key)
+        if hit is None:
             d = self.model.hidden_dim
             unique, ids = relation_ids(edge_texts)
             E = edge_index.size(1)
-            bn = self.ops.message_config(d, E)[0]
+            bn = self.ops.message_config(d, E, N, **({"exact": True} if exact else {}))[0]
+            kw = {"exact": True} if exact else {}
+            inv = None
             if self.mode == "edges":
                 # contiguous ranges of the edge list; the rows are split evenly for the reduce-scatter / all-gather
                 spec = shard_spec(N, 1, self.world, self.rank, 1)
                 lo, hi = E * self.rank // self.world, E * (self.rank + 1) // self.world
-                self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, edge_range=(lo, hi))
+                plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, edge_range=(lo, hi), **kw)
                 deg = torch.bincount(edge_index[1].to(device), minlength=N).clamp_(min=1)
-                self._inv = (1.0 / deg.to(torch.float32)).contiguous()
+                inv = (1.0 / deg.to(torch.float32)).contiguous()
             else:
                 block_edges = None
                 if self.balance == "edges":
                     nb = -(-N // bn)
                     block_edges = torch.bincount(torch.div(edge_index[1], bn, rounding_mode="floor"), minlength=nb).cpu().tolist()
                 spec = shard_spec(N, bn, self.world, self.rank, self.chunks, block_edges)
-                self._plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, **spec.owner_arg())
-            self._spec, self._plan_key, self._keep = spec, key, (edge_index, edge_texts)
+                plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, **spec.owner_arg(), **kw)
+            hit = (plan, spec, inv, (edge_index, edge_texts))
+            while len(self._plans) >= 4:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = hit
+        self._plan, self._spec, self._inv = hit[0], hit[1], hit[2]
         return self._plan
 
     # -- forward ----------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, node_features: torch.Tensor, edge_index: torch.Tensor, edge_texts: List[str]) -> torch.Tensor:
-        model = self.model
         if edge_index.size(1) != len(edge_texts):
             raise ValueError(f"edge_index has {edge_index.size(1)} edges but edge_texts has {len(edge_texts)} entries")
         N, device = node_features.size(0), node_features.device
         plan = self.plan_for(edge_index, edge_texts, N, device)
-        spec = self._spec
-        d = model.hidden_dim
+        guard = isinstance(self.ops, NativeOps) and self.model._guarded(plan) and self.profile == "full"
+        if guard:
+            flag = _native.range_flag(device)
+            flag.zero_()
+        out = self._forward_on(node_features, plan)
+        self.last_range_flags = 0
+        if guard:
+            # every rank must take the same decision: the guard bits are OR-ed across the ranks (one small collective: MAX
+            # per bit — a MAX of the words would turn {1, 2} into 2)
+            word = flag.cpu() if self.backend == "gloo" else flag
+            bits = torch.stack([(word >> i) & 1 for i in range(3)]).flatten()
+            dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+            word = sum(int(b) << i for i, b in enumerate(bits.tolist()))
+            self.last_range_flags = word
+            if word:
+                # Some row of h or some relation's weights spans more dynamic range than two fp16 pieces hold (include/ghf.h:
+                # ghf_set_range_flag).  The single-GPU forward reruns on the exact fp32 kernels (HyperGNN._forward_exact), and
+                # so does this one — on every rank, since the reduced word is the same everywhere: the same shards planned for
+                # the exact kernels (reference: plain fp32 bmm, hypergnn.py:202,228).
+                old = _native._rs_exact_override
+                _native._rs_exact_override = True
+                try:
+                    out = self._forward_on(node_features, self.plan_for(edge_index, edge_texts, N, device, exact=True))
+                finally:
+                    _native._rs_exact_override = old
+        return out
+
+    def _forward_on(self, node_features: torch.Tensor, plan: GraphPlan) -> torch.Tensor:
+        model, spec = self.model, self._spec
+        N, device, d = node_features.size(0), node_features.device, model.hidden_dim
         self.stats = {"bytes_recv": 0.0}
         # fresh buffers per call (the result is a view of one of them); pad rows are exchanged but never read
         h = torch.empty(spec.padded_rows, d, dtype=torch.float32, device=device)
         h_next = torch.empty_like(h)
         text_embs = self.ops.text_embs(model, plan.unique_texts, device)
-        guard = isinstance(self.ops, NativeOps) and model._guarded(plan) and self.profile == "full"
-        if guard:
-            flag = _native.range_flag(device)
-            flag.zero_()
         if self.mode == "edges":
-            out = self._forward_edges(node_features, plan, spec, text_embs, h, h_next)
-        elif self.ops.exchanges_split(plan):
-            out = self._forward_split(node_features, plan, spec, text_embs, h, h_next)
-        else:
-            out = self._forward_rows(node_features, plan, spec, text_embs, h, h_next)
-        if guard:
-            # every rank must take the same decision: the flags are OR-ed across the ranks (one 4-byte collective)
-            bits = flag.cpu() if self.backend == "gloo" else flag
-            dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
-            if int(bits.item()):
-                raise RuntimeError("ShardedHyperGNN: the range guard of the two-fp16-piece kernels fired (include/ghf.h: "
-                                   "ghf_set_range_flag); run the sharded forward with GHF_KERNEL=pp (exact kernels)")
-        return out
+            return self._forward_edges(node_features, plan, spec, text_embs, h, h_next)
+        if self.ops.exchanges_split(plan):
+            return self._forward_split(node_features, plan, spec, text_embs, h, h_next)
+        return self._forward_rows(node_features, plan, spec, text_embs, h, h_next)
 
     def _forward_rows(self, node_features, plan, spec, text_embs, h, h_next) -> torch.Tensor:
         model, N, device = self.model, node_features.size(0), node_features.device

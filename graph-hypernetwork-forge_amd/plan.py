@@ -93,12 +93,27 @@ SRC_MASK = 0x0FFFFFFF
 D64_PIECES_MIN_EDGES = 500_000
 
 
-def plan_config(d: int, E: int) -> Tuple[int, int, int, int]:
-    """(block_nodes, weight layout, chunk_rows, split_chunks) build_plan uses for a graph of E edges (all of them: every rank
-    of a sharded run passes the whole graph's count): ghf_message_config, but small hidden-64 graphs keep the exact kernel."""
+CSR_CONFIG = (1, _native.WLAYOUT_NATURAL, 0, 0)      # no destination blocks: relation-stationary layer or generic kernel
+
+
+def block_kernel_max_nodes(d: int, wlayout: int) -> int:
+    """How many rows of h a destination-block kernel can address: their gathers use 32-bit byte offsets into the row table
+    (csrc/message_bx.hip / message_hx.hip: N (4d + 4) bytes of split rows and scales; message_pp.hip: N 4d bytes of fp32
+    rows), 4 GiB less the page the kernels point dead rows at.  d = 128: 8.3 M rows."""
+    per_row = 4 * d + (4 if wlayout in _native.SPLIT_LAYOUTS else 0)
+    return ((1 << 32) - 4096) // per_row
+
+
+def plan_config(d: int, E: int, N: Optional[int] = None) -> Tuple[int, int, int, int]:
+    """(block_nodes, weight layout, chunk_rows, split_chunks) build_plan uses for a graph of E edges and N nodes (the whole
+    graph's counts: every rank of a sharded run holds all rows of h): ghf_message_config, but small hidden-64 graphs keep the
+    exact kernel, and graphs with more rows than the block kernels' 32-bit row offsets reach (block_kernel_max_nodes) get a
+    CSR plan — the relation-stationary layer (d % 128 == 0) or the generic kernel, both on 64-bit row indices."""
     cfg = _native.message_config(d)
     if d == 64 and cfg[1] == _native.WLAYOUT_SPLIT2H and not os.environ.get("GHF_KERNEL") and E < D64_PIECES_MIN_EDGES:
         cfg = _native.exact_config(d)                    # see D64_PIECES_MIN_EDGES
+    if N is not None and cfg[0] > 1 and N > block_kernel_max_nodes(d, cfg[1]):
+        cfg = CSR_CONFIG
     return cfg
 
 
@@ -278,8 +293,10 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
     R = len(unique_texts)
     if exact:                                     # the exact fp32 kernels (range guard fallback: _native.exact_config)
         bn, wl, cr, sc = _native.exact_config(d)
+        if bn > 1 and N > block_kernel_max_nodes(d, wl):
+            bn, wl, cr, sc = CSR_CONFIG
     else:
-        bn, wl, cr, sc = (1, _native.WLAYOUT_NATURAL, 0, 0) if force_generic else plan_config(d, edge_index.size(1))
+        bn, wl, cr, sc = CSR_CONFIG if force_generic else plan_config(d, edge_index.size(1), N)
     ei = edge_index.to(device=device, dtype=torch.int64).contiguous()
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
     lo, hi = (0, N) if row_range is None else row_range

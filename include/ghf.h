@@ -179,16 +179,26 @@ size_t ghf_weights_bytes(int R, int d_in, int d_out, int wlayout);
  * GHF_WLAYOUT_SPLIT2H rows and weights keep 22 significand bits of every element within 2^-14 of the largest magnitude of
  * their row (activations) or of their relation's [2d, d] matrix (weights); an element further down loses one bit per
  * factor of two and vanishes below 2^-38 of the largest.  Bound on a product sum_k x_k w_k: 3 * 2^-22 * sum |x_k w_k|
- * (the order of the fp32 fma chain it replaces) + 2^-37 * max|x| * sum_k |w_k| over the far-down x_k (and the same with x
+ * (the order of the fp32 fma chain it replaces) + 2^-38 * max|x| * sum_k |w_k| over the far-down x_k (and the same with x
  * and w exchanged).  The second term is invisible unless the large entries meet (near-)zero partners, e.g. one feature
  * 2^30 above the rest whose weight column is 0 — the reference's fp32 bmm (hypergnn.py:202,228) has no such case.
- * Every kernel that cuts rows or weights therefore counts, per row / per relation matrix (per 32 x 32 tile in
- * ghf_weights_pack_rs), the nonzero entries more than 2^14 below the largest; when they are at least 1/8 of the nonzero
- * entries it ORs GHF_RANGE_ROWS / GHF_RANGE_WEIGHTS into the int32 device word registered here (NULL: no guard).  The
- * word belongs to the caller, who clears it before a forward and reads it after (the host mirror then repeats the forward
- * on the exact fp32 kernels).  One word per process (one process drives one GPU). */
+ * Three conditions are watched by every kernel that cuts rows or weights; each ORs a bit into the int32 device word
+ * registered here (NULL: no guard):
+ *   GHF_RANGE_ROWS / GHF_RANGE_WEIGHTS — per row / per relation matrix (per 32 x 32 tile in ghf_weights_pack_rs) the nonzero
+ *     entries more than 2^14 below the largest are at least 1/8 of the nonzero entries;
+ *   GHF_RANGE_WEAK_W — some relation's [W_msg; W_self] has an input row whose L1 norm is below d * 2^-16 of the largest
+ *     row's (a half that is zero throughout, as in the backward's GHF_FLAG_ZERO_* passes, takes no part).
+ * GUARANTEE while GHF_RANGE_WEAK_W is clear (s[k] = L1 norm of input row k, all s[k] >= d 2^-16 max s): summed over a
+ * result row's d outputs, the second term is at most 2^-38 * max|x| * d * max s on either side, and sum_o sum_k |x_k w_ko| =
+ * sum_k |x_k| s[k] >= max|x| * d 2^-16 * max s — i.e. the whole error stays within 4 * 2^-22 * sum |x_k w_ko|, the kind
+ * of bound the fp32 fma chain has, however few or many entries of a row or a matrix lie far down.  A matrix with a weak
+ * row is where a far-down entry can carry a result on its own (rows whose large entries meet that row); generated dense
+ * weights do not have one.
+ * The word belongs to the caller, who clears it before a forward and reads it after (the host mirror then repeats the
+ * forward on the exact fp32 kernels when any bit is set).  One word per process (one process drives one GPU). */
 #define GHF_RANGE_ROWS 1
 #define GHF_RANGE_WEIGHTS 2
+#define GHF_RANGE_WEAK_W 4
 int ghf_set_range_flag(int32_t* device_word);
 
 /* ---- K3 alone -------------------------------------------------------------------------

@@ -29,10 +29,10 @@ class OracleOps:
         self.bn = block_nodes
         self.split = split           # emulate a kernel that gathers a split form: here the fp32 bits + a row "scale" of 1
 
-    def message_config(self, d, E):
+    def message_config(self, d, E, N=None, exact=False):
         return self.bn, 0, 48, 128
 
-    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner=None, owner_bounds=None, edge_range=None):
+    def build_plan(self, edge_index, rel_ids, unique, N, d, device, owner=None, owner_bounds=None, edge_range=None, exact=False):
         if edge_range is not None:                                   # edge-range shards: a slice of the edge list
             keep = torch.zeros(edge_index.size(1), dtype=torch.bool)
             keep[edge_range[0]:edge_range[1]] = True

@@ -1240,6 +1240,70 @@ def test_range_guard_routes_wide_inputs_to_the_exact_kernels(d, what, monkeypatc
     assert model3.last_range_flags == 0
 
 
+def _blind_spot_model(d, F, small, what):
+    """The case the 1/8 rule does not see: only `small` of d entries (10 %) lie far below the rest.
+    rows: layer 0's generated W_msg / W_self are zero on the LARGE input columns, so the far-down entries of an outlier row
+    carry its whole message; weights: layer 0's matrices are 2^30 larger on input rows >= small, which only ever meet zeros."""
+    cfg = cases.ModelCfg(text_dim=16, node_feat_dim=F, hidden_dim=d, num_layers=2, seed=911, log_scale=0.0, randomize_ln=True)
+    p = cfg.params()
+    p["input_proj.weight"] = np.eye(d, F, dtype=np.float32)            # h0 = relu(x)
+    p["input_proj.bias"] = np.zeros(d, np.float32)
+    for head in ("W_msg", "W_self"):
+        k = max(int(n.split(".")[4]) for n in p if n.startswith(f"weight_generators.0.generators.{head}."))
+        W, b = p[f"weight_generators.0.generators.{head}.{k}.weight"], p[f"weight_generators.0.generators.{head}.{k}.bias"]
+        if what == "rows":
+            W[small * d:] = 0.0                                        # flat [d*d] = [input k][output o]: rows k >= small
+            b[small * d:] = 0.0
+        else:
+            W[small * d:] *= 2.0 ** 30
+            b[small * d:] *= 2.0 ** 30
+    return cfg, p
+
+
+@pytest.mark.parametrize("d,what", [(128, "rows"), (128, "weights"), (256, "rows"), (256, "weights")])
+def test_range_guard_has_no_blind_spot_below_one_eighth(d, what, monkeypatch):
+    """10 % of a row's (of a relation matrix's) entries 2^30 below the rest, the large ones meeting zeros: fewer than the 1/8
+    GHF_RANGE_ROWS / GHF_RANGE_WEIGHTS count, and still a case two fp16 pieces cannot hold while the reference's fp32 bmm
+    (hypergnn.py:202,228) can.  GHF_RANGE_WEAK_W (a relation matrix with an input row far below the others: include/ghf.h
+    states the bound that holds without one) routes it to the exact kernels; with the guard off the result is wrong."""
+    F, N, E, R = d, 600, 5000, 5
+    small = d // 10
+    cfg, params = _blind_spot_model(d, F, small, what)
+    kg = synth.make_kg(N, E, R, F, seed=37)
+    x = np.abs(kg.node_features).astype(np.float32) + 0.1
+    if what == "rows":
+        x[::3, small:] *= 2.0 ** 30                                      # a third of the rows: 90 % of the columns dwarf the rest
+    else:
+        x[:, small:] = -1.0                                              # relu -> exactly 0 where the huge weights are
+    ei, texts = kg.edge_index, kg.edge_texts()
+    ref = O.forward(params, x, ei, texts, variant="factorised").numpy()
+    model = make_model(cfg, params)
+    with torch.no_grad():
+        out = model(torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), texts)
+    assert model.last_range_flags & _native.RANGE_WEAK_W
+    if what == "rows" or d == 128:       # (wide rows: ghf_weights_pack_rs counts per 32 x 32 tile, and the tiles of the small rows do see them)
+        assert not model.last_range_flags & (_native.RANGE_ROWS if what == "rows" else _native.RANGE_WEIGHTS), "built to stay under the 1/8 count"
+    assert_close(out.cpu().numpy(), ref, f"guarded forward d={d} {what}")
+    monkeypatch.setenv("GHF_RANGE_GUARD", "0")
+    model2 = make_model(cfg, params)
+    with torch.no_grad():
+        raw = model2(torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), texts)
+    with pytest.raises(AssertionError):
+        assert_close(raw.cpu().numpy(), ref, "unguarded")
+    monkeypatch.delenv("GHF_RANGE_GUARD")
+    # the same rows on generic weights (no weak input row): no bit, and the two-piece kernels are within tolerance although
+    # 10 % of those rows' entries lie 2^30 down — the bound of ghf.h
+    if what == "rows":
+        cfg3 = cases.ModelCfg(text_dim=16, node_feat_dim=F, hidden_dim=d, num_layers=2, seed=911, log_scale=0.0, randomize_ln=True)
+        p3 = cfg3.params()
+        p3["input_proj.weight"], p3["input_proj.bias"] = np.eye(d, F, dtype=np.float32), np.zeros(d, np.float32)
+        model3 = make_model(cfg3, p3)
+        with torch.no_grad():
+            out3 = model3(torch.from_numpy(x).to(DEV), torch.from_numpy(ei).to(DEV), texts)
+        assert model3.last_range_flags == 0
+        assert_close(out3.cpu().numpy(), O.forward(p3, x, ei, texts, variant="factorised").numpy(), f"generic weights d={d}")
+
+
 def test_forward_ids_equals_forward(golden_dir):
     """The pre-tokenised overload (relation ids + one string per relation) gives the forward's result."""
     (case,) = cases.graph_cases(only=["g3_mid32"])
@@ -1395,45 +1459,133 @@ def test_full_size_c5_shard_properties(runs):
 
 # ---- the multi-GPU driver on one GPU: NCCL world of 1, 4 overlapped chunks ------------------------------
 
-def _two_rank_worker(rank, world, port, name, ret):
+def _adversarial_graph(d):
+    """Inputs and model of test_range_guard_routes_wide_inputs_to_the_exact_kernels (rows)."""
+    cfg, params = _adversarial_model(d, d, rows_outlier=True)
+    kg = synth.make_kg(600, 5000, 5, d, seed=31)
+    x = np.abs(kg.node_features).astype(np.float32) + 0.1
+    x[::3, 0] *= 2.0 ** 30
+    return cfg, params, x, kg.edge_index, kg.edge_texts()
+
+
+def _two_rank_worker(rank, world, port, name, ret, kw):
     import torch.distributed as dist
     from graph_hypernetwork_forge_amd.dist import ShardedHyperGNN
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        (case,) = cases.graph_cases(only=[name])
-        model = make_model(cases.MODELS[case.model])
-        runner = ShardedHyperGNN(model, chunks=3)                        # the product ops: HIP kernels on every rank
-        x, ei = torch.from_numpy(case.node_features).to(DEV), torch.from_numpy(case.edge_index).to(DEV)
-        out = runner(x, ei, case.edge_texts)
-        out2 = runner(x, ei, case.edge_texts)
+        if name.startswith("adversarial"):
+            cfg, params, feats, ei_np, texts = _adversarial_graph(int(name.split(":")[1]))
+            model = make_model(cfg, params)
+        else:
+            (case,) = cases.graph_cases(only=[name])
+            model = make_model(cases.MODELS[case.model])
+            feats, ei_np, texts = case.node_features, case.edge_index, case.edge_texts
+        runner = ShardedHyperGNN(model, chunks=3, **kw)                  # the product ops: HIP kernels on every rank
+        x, ei = torch.from_numpy(feats).to(DEV), torch.from_numpy(ei_np).to(DEV)
+        out = runner(x, ei, texts)
+        out2 = runner(x, ei, texts)
         torch.cuda.synchronize()
         assert torch.equal(out, out2)
-        ret[rank] = out.cpu().numpy()
+        ret[rank] = (out.cpu().numpy(), runner.last_range_flags, runner._plan.E)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("g6_c3", 2), ("g5_c2", 3), ("g6_c3", 3)])
-def test_sharded_forward_multi_rank_on_one_gpu(golden_dir, name, world):
-    """The whole multi-rank product path — ownership-filtered plans, chunked launches, per-layer exchange (of the split
-    rows the fused tails write at d = 128, of fp32 rows plus a re-split at d = 64) — with real HIP kernels on every rank: `world` processes share this GPU and exchange
-    through gloo (NCCL refuses two ranks on one device); every rank must reproduce the reference."""
+def _run_ranks(world, name, kw):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_two_rank_worker, args=(world, port, name, ret), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, port, name, ret, kw), nprocs=world, join=True)
     assert sorted(ret.keys()) == list(range(world))
+    return [ret[r] for r in range(world)]
+
+
+@pytest.mark.parametrize("name,world,kw", [
+    ("g6_c3", 2, {}), ("g5_c2", 3, {}), ("g6_c3", 3, {}),
+    # BASELINE config 4 as written: contiguous edge ranges, raw partial sums of ALL rows from the product kernels
+    # (GHF_FLAG_RAW_SUM on an edge_range plan: blocks without edges on a rank must come out zero, split blocks combine
+    # under a rank-local in-degree), reduction, mean + tail on the owned rows, all-gather
+    ("g6_c3", 2, dict(mode="edges")), ("g6_c3", 3, dict(mode="edges")), ("g5_c2", 2, dict(mode="edges")),
+    ("g6_c3_powerlaw", 2, dict(mode="edges")), ("g7_c5", 2, dict(mode="edges")),
+    # every rank sends its slot straight to each peer; slots of about equal in-edge counts on a power-law graph
+    ("g6_c3", 2, dict(exchange="pairs")), ("g5_c2", 3, dict(exchange="pairs")),
+    ("g6_c3_powerlaw", 3, dict(balance="edges")), ("g6_c3_powerlaw", 2, dict(balance="edges")), ("g7_c5", 2, dict(balance="edges")),
+])
+def test_sharded_forward_multi_rank_on_one_gpu(golden_dir, name, world, kw):
+    """The whole multi-rank product path — ownership-filtered (or edge-range) plans, chunked launches, per-layer exchange
+    (of the split rows the fused tails write at d = 128, of fp32 rows plus a re-split at d = 64, of raw partial sums in
+    mode="edges") — with real HIP kernels on every rank: `world` processes share this GPU and exchange through gloo (NCCL
+    refuses two ranks on one device); every rank must reproduce the reference (BASELINE configs 3-5)."""
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    res = _run_ranks(world, name, kw)
+    if kw.get("mode") == "edges":
+        (case,) = cases.graph_cases(only=[name])
+        assert sum(r[2] for r in res) == case.edge_index.shape[1] and min(r[2] for r in res) > 0, "every rank holds a range of the edges"
     for r in range(world):
         if "out" in g:
-            assert_close(ret[r], g["out"], f"{name} world={world} rank={r}")
+            assert_close(res[r][0], g["out"], f"{name} world={world} {kw} rank={r}")
         else:
-            assert_close(ret[r][g["rows"]], g["out_rows"], f"{name} world={world} rank={r} rows")
-        assert np.array_equal(ret[r], ret[0])
+            assert_close(res[r][0][g["rows"]], g["out_rows"], f"{name} world={world} {kw} rank={r} rows")
+        assert np.array_equal(res[r][0], res[0][0])
+        assert res[r][1] == 0
+
+
+@pytest.mark.parametrize("d,kw", [(128, {}), (128, dict(mode="edges")), (256, {})])
+def test_sharded_forward_falls_back_collectively_when_the_range_guard_fires(d, kw):
+    """Rows the two-fp16-piece kernels cannot hold (one feature 2^30 above the rest, meeting zero weights): the single-GPU
+    forward reruns on the exact kernels, and so does the sharded one — the guard word is reduced over the ranks, every rank
+    plans the same shards for the exact kernels and runs again (reference: plain fp32 bmm, hypergnn.py:202,228)."""
+    cfg, params, x, ei, texts = _adversarial_graph(d)
+    ref = O.forward(params, x, ei, texts, variant="factorised").numpy()
+    res = _run_ranks(2, f"adversarial:{d}", kw)
+    for r in range(2):
+        assert res[r][1] & _native.RANGE_ROWS, "the guard must have fired on some rank and be seen on every rank"
+        assert_close(res[r][0], ref, f"sharded fallback d={d} {kw} rank={r}")
+        assert np.array_equal(res[r][0], res[0][0])
+
+
+def test_block_kernel_rows_beyond_two_gib():
+    """message_bx addressed the split rows with byte offsets that had to stay below 2 GiB (N <= 4.16 M at
+    d = 128).  They now reach 4 GiB - 4 KiB: a graph of 4.3 M nodes whose edges all start in the rows beyond 2 GiB, sampled
+    destinations against a float64 evaluation (reference statement: models/hypergnn.py:201-230, 288-296)."""
+    N, E, R, d = 4_300_000, 1_000_000, 16, 128
+    assert N * (4 * d + 4) > 2 ** 31
+    hi0 = (2 ** 31) // (4 * d) + 1000                                   # first row wholly beyond 2 GiB of split rows
+    src = hi0 + synth.randint(21, "src", E, N - hi0)
+    dst = np.concatenate([synth.randint(21, "dst", E // 2, 200_000), hi0 + synth.randint(21, "dst2", E - E // 2, N - hi0)])
+    rel = synth.randint(21, "rel", E, R)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)    # noqa: E731
+    plan = build_plan(t(np.stack([src, dst])), t(rel), [""] * R, N, d, DEV)
+    assert plan.block_nodes == 384 and plan.wlayout == _native.WLAYOUT_SPLIT2H
+    g = torch.Generator(device="cpu").manual_seed(4)
+    h = torch.randn(N, d, generator=g)
+    Wm, Ws = synth.normal(13, "Wm", (R, d, d), std=0.08), synth.normal(13, "Ws", (R, d, d), std=0.08)
+    b = synth.normal(13, "b", (R, d), std=0.3)
+    gamma, beta = np.ones(d, np.float32), np.zeros(d, np.float32)
+    h_d = h.to(DEV)
+    W = _native.weights_pack(t(Wm), t(Ws), False, R, d, _native.WLAYOUT_SPLIT2H)
+    out = torch.empty_like(h_d)
+    _native.message_layer_fwd(h_d, plan, W, None, t(b), plan.wlayout, t(gamma), t(beta), 1e-5, out)
+    torch.cuda.synchronize()
+    rows = np.unique(np.concatenate([dst[:150], dst[-150:]]))
+    keep = np.isin(dst, rows)
+    s_src, s_dst, s_rel = (torch.from_numpy(a[keep]) for a in (src, dst, rel))
+    pos = torch.full((N,), -1, dtype=torch.int64)
+    pos[torch.from_numpy(rows)] = torch.arange(len(rows))
+    acc = torch.zeros(len(rows), d, dtype=torch.float64)
+    for r in torch.unique(s_rel).tolist():
+        e = (s_rel == r).nonzero().flatten()
+        c = (h[s_src[e]].double() @ torch.from_numpy(Wm[r]).double() + torch.from_numpy(b[r]).double()
+             + h[s_dst[e]].double() @ torch.from_numpy(Ws[r]).double())
+        acc.index_add_(0, pos[s_dst[e]], c)
+    cnt = torch.from_numpy(np.maximum(np.bincount(dst, minlength=N)[rows], 1)).double()[:, None]
+    xr = torch.relu(acc / cnt + h[torch.from_numpy(rows)].double())
+    ref = torch.nn.functional.layer_norm(xr, (d,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5)
+    assert_close(out[t(rows)].cpu().numpy(), ref.numpy(), "rows whose sources lie beyond 2 GiB of split rows")
 
 
 def test_sharded_driver_single_rank_nccl(golden_dir):

@@ -234,3 +234,20 @@ def test_header_is_plain_c_and_binds_from_c(tmp_path):
     out = subprocess.run([exe, _native.lib_path()], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.strip() == f"ok {_native.ABI_VERSION}"
+
+
+def test_plan_config_routes_graphs_beyond_the_block_kernels_row_offsets_to_a_csr_plan():
+    """the destination-block kernels gather rows through 32-bit byte offsets; graphs with more rows than those
+    reach must get a CSR plan (relation-stationary layer / generic kernel, 64-bit row indices) instead of an EINVAL at the
+    first layer — `bench.py --weak` runs N = 1 M x world rows."""
+    from graph_hypernetwork_forge_amd import _native, plan
+    bn, wl, _, _ = plan.plan_config(128, 10_000_000, 1_000_000)
+    assert bn == 384 and wl == _native.WLAYOUT_SPLIT2H
+    lim = plan.block_kernel_max_nodes(128, wl)
+    assert 8_000_000 < lim < (1 << 32) // 516 and lim * 516 <= 0xFFFFF000
+    assert plan.plan_config(128, 80_000_000, 8_000_000)[0] == 384           # bench.py --weak at 8 ranks
+    assert plan.plan_config(128, 80_000_000, lim)[0] == 384
+    assert plan.plan_config(128, 80_000_000, lim + 1) == plan.CSR_CONFIG
+    assert plan.plan_config(64, 80_000_000, 17_000_000) == plan.CSR_CONFIG
+    assert plan.plan_config(20, 1000, 1 << 40) == plan.CSR_CONFIG          # no block kernel anyway
+    assert plan.block_kernel_max_nodes(128, _native.WLAYOUT_FRAG16) == ((1 << 32) - 4096) // 512
