@@ -35,11 +35,11 @@ if _t:
 _x = _re.search(r"bxexp(\d+)", VARIANT)
 if _x:
     FLAGS.append("-DGHF_BXEXP=" + _x.group(1))         # compile-time ablations of message_bx.hip (timing only)
-for _k in ("U", "UW", "CR", "SB", "RD", "AD", "PK", "YT", "PRIO", "LATE", "DEFER", "SCHED", "FLAGWAIT", "FOLDMASK", "TGB", "TLOADS", "TCOL"):               # message_bx.hip geometry: e.g. GHF_VARIANT=bxU5_bxCR64
+for _k in ("NPW", "CR", "AD", "YT", "PRIO", "LATE", "DEFER", "SCHED", "FLAGWAIT", "TGB", "TLOADS", "TCOL"):               # message_bx.hip geometry: e.g. GHF_VARIANT=bxNPW80_bxCR64
     _g = _re.search(r"bx%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX_%s=%s" % (_k, _g.group(1)))
-for _k in ("U", "CR"):                                  # message_bx.hip, hidden 64: e.g. GHF_VARIANT=b64U3_b64CR128
+for _k in ("NPW", "CR"):                                # message_bx.hip, hidden 64: e.g. GHF_VARIANT=b64NPW96_b64CR128
     _g = _re.search(r"b64%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX64_%s=%s" % (_k, _g.group(1)))

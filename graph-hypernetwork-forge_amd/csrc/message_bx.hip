@@ -6,23 +6,26 @@
 // 512 KB against 160 KB of LDS, and most of it was idle.  Here (d = 128; BxCfg<64> below for hidden 64):
 //
 //   * the block is BN = 384 nodes (chunks of ~60 rows: 1.8x the rows per weight fetch, 0.57x the chunks);
-//   * waves 4-7 (HELPERS) own the block sums: lane l of helper wave hw holds U "units" of UW consecutive sum positions of
-//     a node — unit u = U*l + k is part (u % NU) of node NPW*hw + u / NU, NU = d / UW — as plain VGPRs with compile-time
-//     indices (192 registers per lane at BN = 384);
-//   * waves 0-3 (CONSUMERS) run the contraction exactly as message_hx.hip does (same SPLIT2H weights, same row pieces,
-//     three v_mfma_f32_16x16x32_f16 per product, B fragments in a register ring refilled straight from L2) and write a
-//     chunk's finished rows Y [rows][d] fp32 to an LDS staging tile instead of scattering them;
-//   * the helpers FOLD the staged rows into their registers: a table node -> row (written per chunk) tells every owner
-//     lane which staged row, if any, belongs to its node; it reads that row's part with ds_read_b128 and adds it.  Rows
-//     of one chunk with equal destinations (a run; rows are sorted by destination) are first added into the run's last
-//     row by the wave that owns the destination, in ascending order.  No atomics, no dynamic register index, fixed
-//     order: bitwise reproducible;
+//   * waves 4-7 (HELPERS) own the block sums: helper wave hw holds the NPW = BN / 4 nodes NPW*hw .. NPW*hw + NPW - 1, lane l the
+//     PL = d / 64 sum positions PL*l .. PL*l + PL - 1 of EVERY one of them, as plain VGPRs pinned to v64 .. v(63 + NPW*PL)
+//     (192 registers per lane at BN = 384);
+//   * waves 0-3 (CONSUMERS) run the contraction (SPLIT2H weights and row pieces, three v_mfma_f32_16x16x32_f16 per product,
+//     B fragments in a register ring refilled straight from L2) and write a chunk's finished rows Y [rows][d] fp32 to an LDS
+//     staging tile instead of scattering them;
+//   * the helpers FOLD the staged rows into their registers ROW BY ROW (round 3): a chunk's rows are sorted by destination,
+//     so the rows of a wave's nodes are one contiguous range; for each of them the wave reads the row — 4 PL bytes per lane,
+//     one conflict-free 256 PL-byte access — and adds it to the registers of the row's node: the node is a run-time but
+//     wave-uniform value, and gfx950's VGPR indexing mode (s_set_gpr_idx_on: the destination and the second source of a
+//     VALU instruction relative to M0) turns that into two instructions per row and lane.  Rows in order, chunks in
+//     order, no atomics: bitwise reproducible.  (Round 2 folded node by node — a table node -> row, every owner lane
+//     reading its node's row or zeros: 48 ds_read_b128 + 96 packed adds per lane and chunk whatever the chunk held,
+//     3,000 + 1,540 of the helpers' 8,700 cycles per chunk: tools/stamps_bx.py.)
 //   * the helpers gather the A tiles with LDS-DMA (buffer_load_dwordx4 ... lds, per-lane source address, 1 KiB per wave
 //     instruction, the XOR swizzle applied on the source side): no staging registers, no ds_write;
 //   * the fused tail runs from LDS after the helpers have dumped their registers there (two halves of the block).
 //
-// LDS: P0[2] (source-row tiles), P1[2] (destination-row tiles), CR * 4d bytes each; table [BN]; four chunk descriptors
-// ("meta": the rows' scales and node ids); a KiB for DMA pieces past a tile, 128 bytes of zeros, eight flag words.
+// LDS: P0[2] (source-row tiles), P1[2] (destination-row tiles), CR * 4d bytes each; four chunk descriptors ("meta": the
+// rows' scales and node ids); a KiB for DMA pieces past a tile, a row of zeros, sixteen flag words.
 // ONE workgroup barrier per chunk.  During chunk k (between barriers k and k + 1):
 //   consumers: stage Y(k-1) into P1[(k-1)&1] (behind the barrier every consumer is through with that tile; flag "staged");
 //              phase 0 (h_src x W_msg) from P0[k&1]; wait for the flag "destination rows of chunk k landed"; phase 1
@@ -30,7 +33,7 @@
 //   helpers:   DMA P0[(k+1)&1] <- source rows of chunk k+1 (HBM: a whole chunk to land); counted vmcnt wait: the destination
 //              rows of chunk k, requested at the end of chunk k-1, are in (flag "landed"); wait for "staged", fold Y(k-1) out
 //              of P1[(k-1)&1]; once all four have folded (flag words), DMA that tile <- destination rows of chunk k+1 (L2; may
-//              land after the barrier); table of chunk k; the descriptor pipeline (chunk_tab entry k+5, edge words k+4, row
+//              land after the barrier); the descriptor pipeline (chunk_tab entry k+5, edge words k+4, row
 //              scales k+3, publish k+2); counted vmcnt wait: the source rows of chunk k+1 are in
 // Template parameter SKIP: the instances for the backward's two gradient passes, whose weights have one zero half
 // (GHF_FLAG_ZERO_SRC / GHF_FLAG_ZERO_DST): that half's gathers and products are compiled out.
@@ -95,17 +98,8 @@ __device__ __forceinline__ int opaque_lane(int lane) {
     return lane + z;
 }
 
-#ifndef GHF_BX_U
-#define GHF_BX_U 6           // units per helper lane
-#endif
-#ifndef GHF_BX_UW
-#define GHF_BX_UW 32         // sum positions per unit
-#endif
-#ifndef GHF_BX_SB
-#define GHF_BX_SB 2          // fold: 16-byte reads per step
-#endif
-#ifndef GHF_BX_RD
-#define GHF_BX_RD 3          // fold: steps in flight (<= 6)
+#ifndef GHF_BX_NPW
+#define GHF_BX_NPW 96        // nodes per helper wave at d = 128 (BN = 4 NPW; two registers per node and lane)
 #endif
 // Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results): 1 no B refills, 2 no A-tile DMA, 4 no MFMAs,
 // 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table), 128 one
@@ -115,9 +109,6 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #endif
 #ifndef GHF_BX_AD
 #define GHF_BX_AD 2          // consumers: A-fragment positions read ahead (2, 4, 6 measured the same)
-#endif
-#ifndef GHF_BX_PK
-#define GHF_BX_PK 1          // fold: v_pk_add_f32 (two per 16 bytes) instead of four v_add_f32: 3.56 -> 3.52 ms at C3
 #endif
 #ifndef GHF_BX_YT
 #define GHF_BX_YT 0
@@ -137,9 +128,6 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_FLAGWAIT
 #define GHF_BX_FLAGWAIT 1      // 1: the staged rows are drained (lgkmcnt) before their flag is set (0 measured the same; kept conservative)
 #endif
-#ifndef GHF_BX_FOLDMASK
-#define GHF_BX_FOLDMASK 0
-#endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
 #endif
@@ -155,8 +143,8 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_TGB
 #define GHF_BX_TGB 3         // tail: four-row groups in flight per wave (six per half at d = 128); measured 1: 3.21, 2: 3.23, 3: 3.18, 4: 3.27 ms
 #endif
-#ifndef GHF_BX64_U
-#define GHF_BX64_U 2         // hidden 64: units per helper lane (block of 128 U nodes) and rows per chunk
+#ifndef GHF_BX64_NPW
+#define GHF_BX64_NPW 64      // hidden 64: nodes per helper wave (one register per node and lane) and rows per chunk
 #endif
 #ifndef GHF_BX64_CR
 #define GHF_BX64_CR 112
@@ -190,22 +178,28 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
 
 template <int D> struct BxCfg;
 template <> struct BxCfg<128> {
-    static constexpr int U = GHF_BX_U, UW = GHF_BX_UW, CR = GHF_BX_CR;
-    static constexpr int BN = 2 * U * UW;          // 4 helper waves x 64 lanes x U units x UW positions / 128
+    static constexpr int NPW = GHF_BX_NPW, CR = GHF_BX_CR;
+    static constexpr int BN = 4 * NPW;             // four helper waves
     static constexpr int MTC = (CR + 15) / 16;     // row tiles per chunk
     static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
-    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 64;
+    static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 512 + 64;
 };
 // hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk decides:
-// long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block (two units per helper
-// lane) so that C2's 100 k nodes still make 391 workgroups for 256 CUs
+// long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block so that C2's 100 k
+// nodes still make 391 workgroups for 256 CUs
 template <> struct BxCfg<64> {
-    static constexpr int U = GHF_BX64_U, UW = 32, CR = GHF_BX64_CR;
-    static constexpr int BN = 4 * U * UW;          // 256 lanes x U units x UW positions / 64
+    static constexpr int NPW = GHF_BX64_NPW, CR = GHF_BX64_CR;
+    static constexpr int BN = 4 * NPW;
     static constexpr int MTC = (CR + 15) / 16;
     static constexpr bool YT = false;
-    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + (size_t)BN * 4 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 128 + 64;
+    static constexpr size_t LDS = (size_t)4 * 2 * CR * 128 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 512 + 64;
 };
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+// The helpers' block sums: tuples of 32 registers pinned to v64 .. — every asm that touches them names them with these
+// constraints, so the register allocator keeps them there and the indexed adds can name v64 + index.
+#define BX_PIN_128(s) "+{v[64:95]}"(s[0]), "+{v[96:127]}"(s[1]), "+{v[128:159]}"(s[2]), "+{v[160:191]}"(s[3]), "+{v[192:223]}"(s[4]), "+{v[224:255]}"(s[5])
+#define BX_PIN_64(s) "+{v[64:95]}"(s[0]), "+{v[96:127]}"(s[1])
 
 struct BxChunk { int r; int e0; int rows; };
 
@@ -223,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     int32_t* __restrict__ range_flag, float* __restrict__ agg_out) {
     using C = BxCfg<D>;
     constexpr int skip = SKIP;
-    constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, U = C::U, UW = C::UW;
+    constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, NPW = C::NPW;
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
     constexpr int KS = D / 32;                // k-steps of 32 per phase
     constexpr int NKS = 2 * KS;
@@ -236,15 +230,16 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr int HROW = NPL * D * 2;         // bytes per node of h_split
     constexpr int CRP = 16 * MTC;             // rows an A tile is read as (the last tile's dead rows are never used)
     constexpr int MSTR = 4 * CRP + 4;         // words per chunk descriptor: sc_u, sc_v, src id, dst id [CRP each], rows
-    constexpr int NU = D / UW;                // units per node
-    constexpr int NPW = BN / TW;              // nodes per helper wave
+    constexpr int PL = D / 64;                // sum positions (registers) per node and helper lane
+    constexpr int NSV = NPW * PL / 32;        // tuples of 32 registers that hold a helper lane's sums
     constexpr int RPP = 1024 / ROWB;          // rows per 1 KiB DMA piece of a plane (4 at d = 128, 8 at d = 64)
     constexpr int LPR = 64 / RPP;             // lanes (16-byte granules) per row of a piece
     constexpr int RBN = CR / RPP;             // pieces per plane
     constexpr int CPL = D / 16;               // tail: columns per lane (16 lanes per row)
     constexpr int RBW = (RBN + TW - 1) / TW;  // pieces per helper wave and plane
     constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
-    static_assert((NTW == 2 || NTW == 1) && CR % RPP == 0 && RPH <= 64 && (32 * U) % NU == 0 && UW % 4 == 0 && NPW * TW == BN, "bad config");
+    static_assert((NTW == 2 || NTW == 1) && CR % RPP == 0 && RPH <= 64 && NPW * TW == BN && (NPW * PL) % 64 == 0 && NPW * PL <= 192 &&
+                      CR <= 128 && (NSV == 6 || NSV == 2) && (D == 128 || D == 64), "bad config");
     // the XOR key of a row's 16-byte granules in an A tile: 16 granules per row at d = 128 (key = row mod 16); 8 at d = 64, where
     // two rows share a 256-byte bank line, so the key is (row / 2) mod 8 — either way the 16 rows of a fragment read hit every
     // bank once
@@ -252,9 +247,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     // P0[2] source-row tiles, P1[2] destination-row tiles; a chunk's staged rows Y overwrite its own P1 tile — or, where
     // five tiles fit (YT: rows per chunk <= 60), have a tile of their own: then neither DMA waits for the fold
     constexpr bool YT = C::YT;
-    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 4 * TILE, TAB_OFF = (YT ? 5 : 4) * TILE, META_OFF = TAB_OFF + BN * 4,
-                       DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: 128 bytes of zeros
-                       FLAG_OFF = ZERO_OFF + 128;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read),
+    constexpr unsigned P0_OFF = 0, P1_OFF = 2 * TILE, Y_OFF = 4 * TILE, META_OFF = (YT ? 5 : 4) * TILE,
+                       DUMMY_OFF = META_OFF + 4 * MSTR * 4, ZERO_OFF = DUMMY_OFF + 1024,       // ZERO: a staged row of zeros (512 bytes)
+                       FLAG_OFF = ZERO_OFF + 512;         // FLAG: 4 helper words (chunks folded), 4 consumer words (chunks whose tiles are read),
                                                           // 4 helper words (chunks whose destination-row tile has landed), 4 consumer
                                                           // words (the last chunk's hand-shake when staging is deferred)
 
@@ -292,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     const uint32_t hsc_off = (uint32_t)((uint64_t)N * HROW);            // the row scales follow the N split rows
 
     // ---- fused tail from LDS (both roles; the helpers dump their registers first, NPW / 2 nodes per wave at a time) ----
-    // dump row v = (NPW/2) * hw + i  <->  node NPW * hw + (NPW/2) * half + i   (helper lanes 32*half .. 32*half + 31)
+    // dump row v = (NPW/2) * hw + i  <->  node NPW * hw + (NPW/2) * half + i
     constexpr int HN = BN / 2, HPW = NPW / 2;
     // 16 lanes per row (a wave works on four rows at a time), CPL = d / 16 adjacent columns per lane: every load and store is
     // 16 bytes per lane, and a row reduction is four DPP steps inside its 16-lane row — for four rows at once.  (One wave
@@ -446,11 +441,12 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     };
 
     if (helper) {
-        float sums[U][UW];                                              // the block sums (see header)
+        f32x32 sm[NSV];                                                 // the block sums (see header): register PL*n + e = position
+#pragma unroll                                                          // PL*lane + e of this wave's node n
+        for (int k = 0; k < NSV; ++k)
 #pragma unroll
-        for (int k = 0; k < U; ++k)
-#pragma unroll
-            for (int i = 0; i < UW; ++i) sums[k][i] = 0.f;
+            for (int i = 0; i < 32; ++i) sm[k][i] = 0.f;
+        if constexpr (D == 128) asm volatile("" : BX_PIN_128(sm)); else asm volatile("" : BX_PIN_64(sm));
         // ================================================ HELPERS ================================================
         const int hw = tw;
         const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)h_split, 0, (int)hsc_off, 0x00020000);
@@ -522,161 +518,90 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             dma_ids(j, which, lane, id);
             dma_issue(tile_off, rows, nt, lane, id);
         };
-        // ---- table: node -> the last row of its run in chunk j (rows sorted by destination) -----------------------
-        auto table_addr = [&](int j, int rows, int lane, int next) -> unsigned {      // destination of my row (next: of the row behind it)
-            const int row = hw * RPH + lane;
-            const int rr = row < rows ? row : rows - 1;
-            return lds0 + meta_off(j) + 4 * (3 * CRP) + 4 * (next && rr + 1 < rows ? rr + 1 : rr);
-        };
-        auto table_store = [&](int rows, int lane, int d0, int d1) {
-            const int row = hw * RPH + lane;
-            if (lane < RPH && row < rows && (row + 1 >= rows || d0 != d1)) lds_st_b32(lds0 + TAB_OFF + 4 * (unsigned)(d0 - (int)node0), row);
-        };
-        auto table_clear = [&](int lane) {
-#pragma unroll
-            for (int i = 0; i < (NPW + 63) / 64; ++i)
-                if (lane + 64 * i < NPW) lds_st_b32(lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + lane + 64 * i), -1);
-        };
-        // ---- fold chunk j's staged rows into the registers -------------------------------------------------------
+        // ---- fold chunk j's staged rows into the registers, row by row -------------------------------------------
         // Y [row][position], the two 32-position halves of a 64-position group swapped when (row >> 2) & 1 (the consumers'
-        // ds_write_b64 of four row groups then touch every bank exactly twice)
-        // Two parts, so that the helpers' work per stage matches the consumers' (tools/stamps_bx.py): fold_prep + the first
-        // half of the units in stage (k,0), the second half in stage (k,1); a per-wave flag in LDS tells the consumers, who
-        // overwrite Y at the end of stage (k,1), that the fold of the previous chunk's rows is complete.
-        auto fold_prep = [&](int j, int rows, int lane, int (&ri)[U]) {
+        // ds_write_b64 of four row groups then touch every bank exactly twice).  The chunk's rows are sorted by destination:
+        // the rows of this wave's nodes are rows [ra, ra + cnt).  Four rows per step: their reads (one 4 PL-byte access per
+        // lane and row), then per row the node's registers += the row, through the VGPR indexing mode: M0[7:0] = PL * node,
+        // destination and second source of the adds relative to it (mode 0xa), base register v64.  M0 also holds the LDS
+        // base of the wave's LDS-DMA instructions: saved and restored around the mode.  Steps past cnt read the row of
+        // zeros into node 0 (no branch inside a step).
+        auto fold_rows = [&](int j, int rows, int lane) __attribute__((always_inline)) {
             const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
             const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
-            // one batch of LDS reads for everything the preparation needs (three dependent round trips of ~250 cycles each
-            // when the run pass's two halves and the table were read one after the other): the destination of row r and of
-            // row r + 1 for both halves of the rows, and the first six table entries of this lane's units
-            constexpr int NP = (CR + 63) / 64;
-            static_assert(NP <= 2 && U <= 12, "run pass: two halves; table reads: two batches of six");
-            unsigned ba[10];
-            int bv[10];
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int r = pass * 64 + lane;
-                const int rr = (pass < NP && r + 1 < rows) ? r : 0;
-                ba[2 * pass] = dd + 4 * rr;
-                ba[2 * pass + 1] = dd + 4 * (rr + 1);
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ba[4 + k] = lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + (U * lane + (k < U ? k : 0)) / NU);
-            lds_ld_b32_x10(ba, bv);
-            // 1. runs of equal destinations owned by this wave: add row r into row r + 1, ascending
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const int r = pass * 64 + lane;
-                const int a = bv[2 * pass], b = bv[2 * pass + 1];
-                const int nl = a - (int)node0 - hw * NPW;
-                unsigned long long mask = __ballot(r + 1 < rows && a == b && nl >= 0 && nl < NPW);
-                while (mask) {
-                    const int r0 = pass * 64 + (int)__builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    if (2 * lane < D) {                     // two positions per lane
-                        const unsigned pa = Y + (unsigned)r0 * (D * 4) + (unsigned)(((2 * lane) ^ (((r0 >> 2) & 1) << 5)) * 4);
-                        const unsigned pb = Y + (unsigned)(r0 + 1) * (D * 4) + (unsigned)(((2 * lane) ^ ((((r0 + 1) >> 2) & 1) << 5)) * 4);
-                        f32x2 x, y;
-                        lds_ld_b64_x2(pa, pb, x, y);
-                        lds_st_b64(pb, x + y);
-                    }
-                }
-            }
-            // 2. every owner lane: the staged row of its node, if any; then the table is free for the next chunk
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (k < U) ri[k] = bv[4 + k];
-#pragma unroll
-            for (int k0 = 6; k0 < U; k0 += 6) {
-                unsigned ta[6];
-                int tv[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) ta[k] = lds0 + TAB_OFF + 4 * (unsigned)(hw * NPW + (U * lane + (k0 + k < U ? k0 + k : 0)) / NU);
-                lds_ld_b32_x6(ta, tv);
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    if (k0 + k < U) ri[k0 + k] = tv[k];
-            }
-            table_clear(lane);
-        };
-        auto fold_units = [&](int j, auto k_lo, auto k_hi, int lane, const int (&ri)[U]) {
-            constexpr int K0 = decltype(k_lo)::value, K1 = decltype(k_hi)::value;
-            const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
-#if GHF_BX_FOLDMASK
-            // (experiment, off: same time — 3.26 vs 3.22-3.29 ms — so the fold is bound neither by LDS bandwidth nor by the zero
-            // reads) only the lanes whose node has a row read and add, unit by unit, each unit behind its own wait
-#pragma unroll
-            for (int k = K0; k < K1; ++k) {
-                const int part = (U * lane + k) % NU, r = ri[k];
-                if (r >= 0) {
-                    const unsigned a = Y + (unsigned)r * (D * 4) + (unsigned)(((part * UW) ^ (((r >> 2) & 1) << 5)) * 4);
-                    f32x4 y8[UW / 4];
-                    static_assert(UW == 32, "eight reads per unit");
-                    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
-                                 "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
-                                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(y8[0]), "=&v"(y8[1]), "=&v"(y8[2]), "=&v"(y8[3]), "=&v"(y8[4]), "=&v"(y8[5]), "=&v"(y8[6]), "=&v"(y8[7])
-                                 : "v"(a) : "memory");
-#pragma unroll
-                    for (int i = 0; i < UW / 4; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sums[k][4 * i + e] += y8[i][e];
-                }
-            }
-            return;
-#endif
-            // the unit's bytes in Y (a lane whose node has no row in this chunk reads — and adds — zeros: no branch)
-            unsigned ua[U];
-#pragma unroll
-            for (int k = K0; k < K1; ++k) {
-                const int part = (U * lane + k) % NU, r = ri[k];
-                ua[k] = r >= 0 ? Y + (unsigned)r * (D * 4) + (unsigned)(((part * UW) ^ (((r >> 2) & 1) << 5)) * 4) : lds0 + ZERO_OFF;
-            }
-            // all 16-byte reads of the lane as one sequence, SB per step, RD steps in flight
-            constexpr int SB = GHF_BX_SB, RD = GHF_BX_RD, RPU = UW / 4, NRD = (K1 - K0) * RPU, NST = NRD / SB;
-            static_assert(NRD % SB == 0, "reads per lane must be a multiple of the step");
-            f32x4 y[RD][SB];
-            auto issue = [&](int st, f32x4 (&dstv)[SB]) {
-#pragma unroll
-                for (int i = 0; i < SB; ++i) {
-                    const int g = st * SB + i;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dstv[i]) : "v"(ua[K0 + g / RPU]), "n"(16 * (g % RPU)) : "memory");
-                }
+            int d0, d1;
+            lds_ld_b32_x2(dd + 4 * lane, dd + 4 * (lane + 64 < CRP ? lane + 64 : CRP - 1), d0, d1);
+            const int base = (int)node0 + hw * NPW;
+            const int n0 = d0 - base, n1 = d1 - base;                    // wave-local node of rows lane, 64 + lane
+            const unsigned long long q0 = __ballot(lane < rows && (unsigned)n0 < (unsigned)NPW);
+            const unsigned long long q1 = __ballot(lane + 64 < rows && (unsigned)n1 < (unsigned)NPW);
+            const int cnt = __builtin_popcountll(q0) + __builtin_popcountll(q1);
+            const int ra = q0 ? (int)__builtin_ctzll(q0) : 64 + (q1 ? (int)__builtin_ctzll(q1) : 0);
+            const unsigned zrow = lds0 + ZERO_OFF + (unsigned)(PL * 4 * lane), lb = (unsigned)(PL * 4 * lane);
+            typedef typename std::conditional<D == 128, f32x2, float>::type yv_t;
+            // Eight rows per step, read as two batches of four: the second lands while the first is added (an LDS round trip is
+            // ~250 cycles here, an indexed add ~12; more rows in flight and the register allocator starts to move the pinned
+            // sums around).  Rows past the end read the row of zeros into node 0.
+            constexpr int FB = 4;
+            int rwin = ra;                                               // first row of the window of 64 being folded
+            auto addr_of = [&](int r0, int i, int m) -> unsigned {       // LDS address of my row r0 + i's part (m: my rows in this window)
+                const int rr = rwin + r0 + i;
+                return r0 + i < m ? Y + (unsigned)rr * (D * 4) + (lb ^ (unsigned)(((rr >> 2) & 1) << 7)) : zrow;
             };
+            auto issue = [&](yv_t (&y)[FB], int r0, int m) __attribute__((always_inline)) {
+                unsigned a[FB];
 #pragma unroll
-            for (int st = 0; st < RD - 1 && st < NST; ++st) issue(st, y[st % RD]);
+                for (int i = 0; i < FB; ++i) a[i] = addr_of(r0, i, m);
+                if constexpr (D == 128)
+                    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"
+                                 : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+                else
+                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7"
+                                 : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+            };
+            // the wait names the batch's registers: nothing may read them above it.  behind: the next batch is in flight
+            auto add_rows = [&](yv_t (&y)[FB], int nsel, int r0, int m, bool behind) __attribute__((always_inline)) {
+                if (behind) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
+                int ix[FB];
 #pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                if (st + RD - 1 < NST) issue(st + RD - 1, y[(st + RD - 1) % RD]);
-                static_assert(SB == 2, "the counted wait below names two destinations");
-                const int left = (NST - 1 - st) < (RD - 1) ? (NST - 1 - st) : (RD - 1);      // steps still in flight behind this one
-                // the wait names this step's destinations: nothing may read them above it
-                if (left == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1])::"memory");
-                else if (left == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(SB) : "memory");
-                else if (left == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(2 * SB) : "memory");
-                else if (left == 3) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(3 * SB) : "memory");
-                else if (left == 4) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(4 * SB) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(y[st % RD][0]), "+v"(y[st % RD][1]) : "n"(5 * SB) : "memory");   // (RD <= 6: lgkmcnt counts to 15)
-#pragma unroll
-                for (int i = 0; i < SB; ++i) {
-                    const int g = st * SB + i, k = K0 + g / RPU, o = 4 * (g % RPU);
-#if GHF_BX_PK
-                    {   // two v_pk_add_f32 instead of four v_add_f32
-                        f32x2 lo2 = (f32x2){sums[k][o], sums[k][o + 1]} + (f32x2){y[st % RD][i][0], y[st % RD][i][1]};
-                        f32x2 hi2 = (f32x2){sums[k][o + 2], sums[k][o + 3]} + (f32x2){y[st % RD][i][2], y[st % RD][i][3]};
-                        sums[k][o] = lo2[0]; sums[k][o + 1] = lo2[1]; sums[k][o + 2] = hi2[0]; sums[k][o + 3] = hi2[1];
-                    }
-#else
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sums[k][o + e] += y[st % RD][i][e];
-#endif
-                    // pin the sums behind this step: otherwise all reads are issued first (192 live registers) and the adds follow
-                    asm volatile("" : "+v"(sums[k][o]), "+v"(sums[k][o + 1]), "+v"(sums[k][o + 2]), "+v"(sums[k][o + 3]));
+                for (int i = 0; i < FB; ++i) ix[i] = PL * __builtin_amdgcn_readlane(nsel, r0 + i);      // (lanes past my rows hold node 0)
+                int keep;
+#define BX_ROW128(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_pk_add_f32 v[64:65], %[y" #i "], v[64:65]\n\t"
+#define BX_ROW64(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_add_f32 v64, %[y" #i "], v64\n\t"
+#define BX_ROW_OPS [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3])
+                if constexpr (D == 128)
+                    asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\tv_pk_add_f32 v[64:65], %[y0], v[64:65]\n\t"
+                                 BX_ROW128(1) BX_ROW128(2) BX_ROW128(3)
+                                 "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
+                                 : BX_PIN_128(sm), [kp] "=&s"(keep) : BX_ROW_OPS);
+                else
+                    asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\tv_add_f32 v64, %[y0], v64\n\t"
+                                 BX_ROW64(1) BX_ROW64(2) BX_ROW64(3)
+                                 "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
+                                 : BX_PIN_64(sm), [kp] "=&s"(keep) : BX_ROW_OPS);
+#undef BX_ROW128
+#undef BX_ROW64
+#undef BX_ROW_OPS
+            };
+            for (int w0 = 0; w0 < cnt; w0 += 64) {                       // (one window unless more than 64 of the chunk's rows are mine)
+                const int m = cnt - w0 < 64 ? cnt - w0 : 64;
+                rwin = ra + w0;
+                // lane i: the node of my row w0 + i
+                const int r = ra + w0 + lane;
+                const int p0 = __builtin_amdgcn_ds_bpermute(4 * (r & 63), n0), p1 = __builtin_amdgcn_ds_bpermute(4 * (r & 63), n1);
+                const int nsel = lane < m ? (r < 64 ? p0 : p1) : 0;
+                // (straight-line per iteration: a batch in flight across a branch or the loop's back edge gets copied by the
+                // compiler — a phi — before its wait, i.e. read before it has landed)
+                for (int g = 0; g < m; g += 2 * FB) {
+                    yv_t ya[FB], yb[FB];
+                    issue(ya, g, m);
+                    issue(yb, g + FB, m);
+                    add_rows(ya, nsel, g, m, true);
+                    add_rows(yb, nsel, g + FB, m, false);
                 }
             }
         };
-        using U0 = std::integral_constant<int, 0>;
-        using U2 = std::integral_constant<int, U>;
         // wait until all four words at `flags` have reached v (the waves of one role run the same program: short waits)
         auto wait_flags = [&](unsigned flags, int v) {
             for (;;) {
@@ -701,8 +626,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         Words wdP{0, 0}, wdN{0, 0}, wdL{0, 0};             // words of chunks k+2 (to publish), k+3, k+4 (just requested)
         Scales scP{1.f, 1.f}, scN{1.f, 1.f};               // scales of chunks k+2, k+3 (just requested)
         i32x2 d5{0, 0};                                    // chunk_tab entry of chunk k+5 (just requested)
-        table_clear(lane);
-        if (hw == 0 && lane < 32 + 16) lds_st_b32(lds0 + ZERO_OFF + 4 * lane, 0);     // zeros and the sixteen flags behind them
+        if (hw == 0)                                                   // the row of zeros and the sixteen flags behind it
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (lane + 64 * i < 128 + 16) lds_st_b32(lds0 + ZERO_OFF + 4 * (lane + 64 * i), 0);
         int prev_rows = 1;
         if (nchunks > 0) {
             i32x2 dd[5];
@@ -733,9 +660,6 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         }
         // DMA instructions per tile and helper wave (constant: dma_tile) — what the counted waits below leave in flight
         constexpr int N_SRC = (skip & 1) ? 0 : RBW * NPL, N_DST = ((skip & 2) || YT) ? 0 : RBW * NPL;
-        int ri[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) ri[k] = -1;
         int sid[6] = {0, 0, 0, 0, 0, 0};                   // source ids of the NEXT chunk's rows (read at the end of a chunk)
         if (nchunks > 0 && !(skip & 1)) dma_ids(1, 2, lane, sid);
         for (int k = 0; k < nchunks; ++k) {
@@ -766,34 +690,17 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
                 if (GHF_BX_DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
-                fold_prep(k - 1, prev_rows, l0, ri);
-                BX_STAMP(5);                               // (stamps: the fold's preparation, apart from its reads and adds)
-                fold_units(k - 1, U0{}, U2{}, l0, ri);
+                BX_STAMP(5);                               // (stamps: the wait for the staged rows)
+                fold_rows(k - 1, prev_rows, l0);
             }
             BX_LGKM0();
-            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k + 1);   // this wave is through with Y(k-1) and the table
-            // what the rest of the chunk reads from the descriptors, in one round trip taken while the other helper waves catch
-            // up: the destination ids of chunk k+1's rows (its tile's DMA) and my row's destination in chunk k (the table)
-            int did[6], td[2];
-            {
-                const int lb = opaque_lane(lane);
-                unsigned ba[10];
-                int bv[10];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) ba[i] = id_addr(k + 1, 3, i, lb);
-                ba[6] = table_addr(k, ch[0].rows, lb, 0);
-                ba[7] = table_addr(k, ch[0].rows, lb, 1);
-                ba[8] = ba[9] = ba[6];
-                lds_ld_b32_x10(ba, bv);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) did[i] = bv[i];
-                td[0] = bv[6];
-                td[1] = bv[7];
-            }
+            if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k + 1);   // this wave is through with Y(k-1)
+            // the destination ids of chunk k+1's rows (its tile's DMA): one round trip taken while the other helper waves catch up
+            int did[6];
+            if (!(skip & 2)) dma_ids(k + 1, 3, opaque_lane(lane), did);
             BX_STAMP(2);
-            // the table of chunk k is written by all helper waves for all of them: every wave must have read (and cleared)
-            // its entries of chunk k-1 first; without a tile of their own the staged rows also sit where the next
-            // destination rows go
+            // without a tile of their own the staged rows sit where the next destination rows go: every helper wave must have
+            // folded them first
             wait_flags(lds0 + FLAG_OFF, k + 1);
             BX_STAMP(3);
             const int l1 = opaque_lane(lane);
@@ -807,7 +714,6 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             d5 = load_desc(k + 5);
             if (!YT && !(skip & 2)) dma_issue(P1_OFF + ((k + 1) & 1) * TILE, ch[1].rows, false, l1, did);
             BX_STAMP(1);
-            if (!(GHF_BXEXP & 64)) table_store(ch[0].rows, l1, td[0], td[1]);
             prev_rows = ch[0].rows;
             if (!(skip & 1)) dma_ids(k + 2, 2, l1, sid);     // (published at this chunk's start by every helper wave; all are past their flag)
             // the source rows of chunk k+1 (requested at this chunk's start) must be in before the barrier; GHF_BX_LATE: the
@@ -822,38 +728,38 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         __builtin_amdgcn_s_barrier();                      // ---- epilogue: the last chunk's rows
         if (nchunks > 0 && !(GHF_BXEXP & 8)) {
             const int le = opaque_lane(lane);
-            fold_prep(nchunks - 1, prev_rows, le, ri);
-            fold_units(nchunks - 1, U0{}, U2{}, le, ri);
+            fold_rows(nchunks - 1, prev_rows, le);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
         BX_LGKM0();
         BX_STAMP(5);
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
-            if ((lane >> 5) == half) {
+        if constexpr (D == 128) asm volatile("" : BX_PIN_128(sm)); else asm volatile("" : BX_PIN_64(sm));
+        // dump row HPW*hw + i = node NPW*hw + HPW*half + i, natural column order: position PL*lane + e is column
+        // 32 (lane / 16) + 16 e + lane % 16 at d = 128 (a consumer wave's two fragments, interleaved), column lane at d = 64
+        // (two explicit halves, not a loop: in a loop body both halves' registers stay live through the first half's tail)
+        auto dump_half = [&](auto half_c) __attribute__((always_inline)) {
+            constexpr int H = decltype(half_c)::value;
+            float* __restrict__ o = (float*)smem + (size_t)(hw * HPW) * D + (D == 128 ? 32 * (lane >> 4) + (lane & 15) : lane);
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int u = U * lane + k, nl = u / NU, part = u % NU;
-                    const unsigned a = lds0 + (unsigned)(hw * HPW + (nl - half * HPW)) * (D * 4) + (unsigned)part * (UW * 4);
-                    // d = 128: position 2x + t of a 32-position group is column 16t + x of it (a consumer wave's two fragments,
-                    // interleaved); d = 64: positions are columns.  The dump is in column order
-                    static_assert(UW == 32, "the dump's position -> column permutation is per 32-position unit");
-                    auto cv = [&](int c) -> float { return NTW == 2 ? sums[k][2 * (c & 15) + (c >> 4)] : sums[k][c]; };
+            for (int i = 0; i < HPW; ++i)
 #pragma unroll
-                    for (int i = 0; i < UW / 4; ++i)
-                        lds_st_b128(a + 16 * i, (f32x4){cv(4 * i), cv(4 * i + 1), cv(4 * i + 2), cv(4 * i + 3)});
+                for (int e = 0; e < PL; ++e) {
+                    const int reg = PL * (H * HPW + i) + e;
+                    o[i * D + 16 * e] = sm[reg / 32][reg % 32];
                 }
-            }
-            BX_LGKM0();
-            __syncthreads();
-            if (half == 0) {
-                tail_half(0, std::integral_constant<int, 1>{});      // (the other half of the sums is still in registers)
-                BX_STAMP(6);
-            } else {
-                tail_half(1, std::integral_constant<int, GHF_BX_TGB>{});
-                BX_STAMP(7);
-            }
-        }
+        };
+        __syncthreads();
+        dump_half(std::integral_constant<int, 0>{});
+        BX_LGKM0();
+        __syncthreads();
+        tail_half(0, std::integral_constant<int, 1>{});              // (the other half of the sums is still in registers)
+        BX_STAMP(6);
+        __syncthreads();
+        dump_half(std::integral_constant<int, 1>{});
+        BX_LGKM0();
+        __syncthreads();
+        tail_half(1, std::integral_constant<int, GHF_BX_TGB>{});
+        BX_STAMP(7);
         BX_STAMP_FLUSH();
     } else {
         // =============================================== CONSUMERS ===============================================

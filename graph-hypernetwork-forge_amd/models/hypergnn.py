@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from .. import _native
 from ..plan import GraphPlan, PlanCache, build_plan, build_rs, exact_plan, relation_ids
-from .weight_generator import WeightGenerator, require_inference, wants_grad
+from .weight_generator import WeightGenerator, check_dropout, draw_mask, require_inference, wants_grad
 
 
 class TextEncoder(nn.Module):
@@ -139,6 +139,7 @@ class HyperGNN(nn.Module):
         super().__init__()
         if num_layers < 1:                                            # reference :123-124
             raise ValueError("num_layers must be at least 1")
+        check_dropout(dropout)
         self.text_dim, self.node_feat_dim, self.hidden_dim = text_dim, node_feat_dim, hidden_dim
         self.num_layers, self.dropout = num_layers, dropout
         self.text_encoder = TextEncoder(text_dim=text_dim, char_emb_dim=char_emb_dim)
@@ -247,7 +248,7 @@ class HyperGNN(nn.Module):
 
     def _draw_mask(self, shape, device) -> torch.Tensor:
         """A dropout mask scaled by 1/(1-p), drawn with torch's generator as F.dropout does in the reference."""
-        return (torch.rand(shape, device=device) >= self.dropout).to(torch.float32) / (1.0 - self.dropout)
+        return draw_mask(shape, device, self.dropout)
 
     def _forward_recorded(self, node_features: torch.Tensor, plan: GraphPlan, edge_index: torch.Tensor) -> torch.Tensor:
         """The forward when gradients are required (reference: plain autograd, demo.py:79-101): the same kernels inside

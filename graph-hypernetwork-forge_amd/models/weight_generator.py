@@ -23,6 +23,20 @@ from .. import _native
 HEADS: Tuple[str, ...] = ("W_msg", "W_self", "bias")     # reference weight_generator.py:72-76
 
 
+def check_dropout(p: float) -> None:
+    """nn.Dropout / F.dropout of the reference raise ValueError outside [0, 1] (weight_generator.py:104, hypergnn.py:293)."""
+    if not 0.0 <= float(p) <= 1.0:
+        raise ValueError(f"dropout probability has to be between 0 and 1, but got {p}")
+
+
+def draw_mask(shape, device, p: float) -> torch.Tensor:
+    """Bernoulli(1 - p) / (1 - p), drawn with torch's generator as F.dropout / nn.Dropout do; p = 1 drops everything (the
+    reference returns zeros there; 0 / 0 would be NaN)."""
+    if p >= 1.0:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    return (torch.rand(shape, device=device) >= p).to(torch.float32) / (1.0 - p)
+
+
 def wants_grad(module: nn.Module, *tensors: torch.Tensor) -> bool:
     """Checks that the inputs live on the HIP device; True when autograd has to record this call."""
     for t in tensors:
@@ -54,6 +68,7 @@ class WeightGenerator(nn.Module):
         super().__init__()
         if text_dim <= 0 or d_in <= 0 or d_out <= 0:             # reference :62-63
             raise ValueError("text_dim, d_in, d_out must all be positive integers")
+        check_dropout(dropout)                                   # (the reference's nn.Dropout(p) raises the same way, :104)
         self.text_dim, self.d_in, self.d_out = text_dim, d_in, d_out
         self.hidden_dim, self.num_hidden, self.dropout = hidden_dim, num_hidden, dropout
         self.init_scale = init_scale
@@ -98,7 +113,7 @@ class WeightGenerator(nn.Module):
 
     def _draw_mask(self, shape, device) -> torch.Tensor:
         """Dropout masks scaled by 1/(1-p), drawn with torch's generator as the reference's nn.Dropout modules do."""
-        return (torch.rand(shape, device=device) >= self.dropout).to(torch.float32) / (1.0 - self.dropout)
+        return draw_mask(shape, device, self.dropout)
 
     def generate_with_grad(self, text_emb: torch.Tensor):
         """Natural-layout (W_msg, W_self, bias) recorded by autograd (backward through the C ABI); in training mode with
@@ -107,7 +122,9 @@ class WeightGenerator(nn.Module):
         dims = (self.text_dim, self.hidden_dim, self.num_hidden, self.d_in, self.d_out)
         if self._dropping():
             masks = self._draw_mask((3, self.num_hidden, text_emb.size(0), self.hidden_dim), text_emb.device)
-            log_keep = torch.full((1,), -math.log(1.0 - self.dropout), dtype=torch.float32, device=text_emb.device)
+            # (p = 1: every unit is dropped and its gradient is zero whatever the factor: 0, not log(1/0))
+            log_keep = torch.full((1,), -math.log(1.0 - self.dropout) if self.dropout < 1.0 else 0.0, dtype=torch.float32,
+                                  device=text_emb.device)
             dims = dims + (masks, log_keep)
         return WeightGeneratorFn.apply(dims, text_emb, *(self.log_scales[h] for h in HEADS), *self._head_parameters())
 

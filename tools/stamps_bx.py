@@ -27,7 +27,7 @@ fn = lib.ghf_debug_read_stamps_bx; fn.restype = ctypes.c_int; fn.argtypes = [cty
 assert fn(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
 for role, sl, names in (("consumers", slice(0, 4), ["barrier wait", "phase-0: unscale+rest", "phase-1: unscale+rest", "staging writes", "stage prologue", "k-step MFMAs", "epilogue + first half of the tail", "B refill issue"]),
-                        ("helpers", slice(4, 8), ["barrier wait", "DMA issue", "fold: reads + adds", "wait for the other helpers", "descriptor work + DMA landing", "fold preparation (run pass, table; + the epilogue's fold)", "tail: first half", "tail: second half"])):
+                        ("helpers", slice(4, 8), ["barrier wait", "DMA issue", "fold (rows into registers)", "wait for the other helpers", "descriptor work + DMA landing", "wait for the staged rows (+ the epilogue's fold)", "tail: first half", "tail: second half"])):
     x = st[:, sl]
     tot = x.sum()
     print(f"{role}: mean cycles per wave {x.sum(axis=2).mean():.0f}")
