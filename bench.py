@@ -32,7 +32,10 @@ import numpy as np
 import torch
 
 WORKLOADS = {
-    # name: N, E, R, d, L, T
+    # name: N, E, R, d, L, T (F: node feature width when it differs from d)
+    # BASELINE config 1: the reference's own demo (demo.py:49-66) — the ToyKnowledgeGraph fixture, launch-latency bound
+    "c1": dict(N=8, E=11, R=7, d=32, L=2, T=64, F=16, seed=42, kind="toy",
+               desc="ToyKnowledgeGraph 8 nodes / 11 edges / 7 rel, feat 16, hidden 32, L=2 (BASELINE config 1, demo.py:49-66)"),
     "c3": dict(N=1_000_000, E=10_000_000, R=64, d=128, L=3, T=64, seed=1003,
                desc="synthetic uniform KG 1M nodes / 10M edges / 64 rel, hidden 128, L=3 (BASELINE config 3)"),
     "c2": dict(N=100_000, E=1_000_000, R=32, d=64, L=2, T=64, seed=1002,
@@ -63,6 +66,20 @@ def kern_name(plan, d):
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
+PMC_FILES = {"c3": "r03_message_kernel_pmc.json", "c2": "r03_c2_kernel_pmc.json", "c5": "r03_c5_kernel_pmc.json"}
+PMC_SOURCES = {"c3": ["message_bx.hip"], "c2": ["message_bx.hip", "message_pp.hip"], "c5": ["message_rs.hip"]}
+
+
+def source_digest(files) -> str:
+    """sha256 over the kernel sources a PMC file was measured on (tools/pmc.sh stores it; a profile of other code is stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "graph-hypernetwork-forge_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -82,6 +99,19 @@ def cpu_baseline(cfg, budget_s=12.0, full=None):
     from graph_hypernetwork_forge_amd import synth
     from oracle import hypergnn_oracle as O
     d, R, L, T = cfg["d"], cfg["R"], cfg["L"], cfg["T"]
+    if cfg.get("kind") == "toy":                           # config 1: the reference's demo forward on the same toy graph
+        xf, eif, tf = full
+        params = synth.hypergnn_params(T, cfg["F"], d, L, seed=7)
+        for _ in range(20):
+            O.forward(params, xf, eif, tf, variant="reference")
+        t0, n = time.time(), 0
+        while time.time() - t0 < min(budget_s, 5.0):
+            O.forward(params, xf, eif, tf, variant="reference")
+            n += 1
+        t = (time.time() - t0) / n
+        return {"value": len(tf) / t, "unit": "edges/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
+                "sample": f"oracle forward (reference op sequence) on the ToyKnowledgeGraph itself, mean of {n} runs",
+                "ms_per_forward": t * 1e3}
     # the reference materialises 4*E*d^2*4 bytes: size the sample to ~8 GB of that
     E = int(min(cfg["E"], max(2000, 8e9 / (16 * d * d))))
     N = max(100, E // 10)
@@ -169,14 +199,21 @@ def main():
     N, E, R, d, L, T = (cfg[k] for k in ("N", "E", "R", "d", "L", "T"))
 
     t0 = time.time()
-    ei_np, rel_np = synth.make_graph_arrays(N, E, R, cfg["seed"], cfg.get("kind", "uniform"))
-    names = synth.relation_names(R)
-    edge_texts = [names[i] for i in rel_np.tolist()]
-    edge_index = torch.from_numpy(ei_np).to(dev)
-    gen = torch.Generator(device=dev).manual_seed(cfg["seed"])
-    x = torch.randn(N, d, generator=gen, device=dev)     # throughput is value-independent
+    F = cfg.get("F", d)
+    if cfg.get("kind") == "toy":
+        from graph_hypernetwork_forge_amd import ToyKnowledgeGraph
+        kg = ToyKnowledgeGraph(feat_dim=F)
+        ei_np, edge_texts = kg.edge_index.numpy(), list(kg.edge_texts)
+        edge_index, x = kg.edge_index.to(dev), kg.node_features.to(dev)
+    else:
+        ei_np, rel_np = synth.make_graph_arrays(N, E, R, cfg["seed"], cfg.get("kind", "uniform"))
+        names = synth.relation_names(R)
+        edge_texts = [names[i] for i in rel_np.tolist()]
+        edge_index = torch.from_numpy(ei_np).to(dev)
+        gen = torch.Generator(device=dev).manual_seed(cfg["seed"])
+        x = torch.randn(N, F, generator=gen, device=dev)     # throughput is value-independent
     torch.manual_seed(0)
-    model = HyperGNN(text_dim=T, node_feat_dim=d, hidden_dim=d, num_layers=L).to(dev).eval().requires_grad_(False)
+    model = HyperGNN(text_dim=T, node_feat_dim=F, hidden_dim=d, num_layers=L).to(dev).eval().requires_grad_(False)
     t_setup = time.time() - t0
 
     runner = None
@@ -310,11 +347,17 @@ def main():
         # HBM-side traffic per launch from the committed rocprofv3 PMC passes of this same command (separate
         # --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read)
         traffic, traffic_src = None, None
-        pmc_name = {"c3": "r02_message_kernel_pmc.json", "c2": "r02_c2_kernel_pmc.json", "c5": "r02_c5_kernel_pmc.json"}[args.workload]
+        pmc_name = PMC_FILES.get(args.workload, "")
         pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         pmc = {}
-        if world == 1 and os.path.exists(pmc_path):
+        if world == 1 and pmc_name and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
+            # counters of an earlier build of the kernels say nothing about this one: tools/pmc.sh stores a
+            # digest of the kernel sources it measured; the traffic figure is dropped when the sources have moved on
+            if pmc.get("_source_sha256") != source_digest(PMC_SOURCES[args.workload]):
+                traffic_src = (f"none: profiles/{pmc_name} was measured on other kernel sources (digest "
+                               f"{pmc.get('_source_sha256')}); rerun tools/pmc.sh")
+                pmc = {}
             names = [pmc.get("_kernel", "")] if "kernels" not in pmc else list(pmc["kernels"])
             want = ["edge_transform", "segment_tail"] if (plan.block_nodes == 1 and _native.rs_supported(d)) else [kern_name(plan, d)]
             if not all(any(w_ in n for n in names) for w_ in want):

@@ -567,8 +567,9 @@ def group_outer(A: Optional[torch.Tensor], ia: Optional[torch.Tensor], B: torch.
 
 
 def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, slice_tab: torch.Tensor,
-               slice_off: torch.Tensor, R: int):
-    """(dW [R, 2d, d] = dW_msg stacked on dW_self, db [R, d]) of include/ghf.h: ghf_edge_outer."""
+               slice_off: torch.Tensor, R: int, exact: bool = False):
+    """(dW [R, 2d, d] = dW_msg stacked on dW_self, db [R, d]) of include/ghf.h: ghf_edge_outer (exact: the fp32 chain at
+    every d — a step that fell back to the exact kernels)."""
     lib = load()
     h, G = _req(h, torch.float32, "h"), _req(G, torch.float32, "G")
     d, ns = h.size(1), slice_tab.size(0)
@@ -578,7 +579,7 @@ def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.T
     db = torch.empty(R, d, dtype=torch.float32, device=h.device)
     _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), _ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")),
                               _ptr(_req(slice_tab, torch.int64, "slice_tab")), _ptr(_req(slice_off, torch.int64, "slice_off")),
-                              ns, R, d, h.size(0), _ptr(ws), _ptr(dW), _ptr(db), _stream()), "ghf_edge_outer")
+                              ns, R, d, 0 if exact else h.size(0), _ptr(ws), _ptr(dW), _ptr(db), _stream()), "ghf_edge_outer")
     return dW, db
 
 

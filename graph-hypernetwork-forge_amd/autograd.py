@@ -52,12 +52,15 @@ class TrainPlan:
 SLICE_EDGES = 4096                # edges per ghf_edge_outer workgroup (a multiple of its 32-edge tile)
 
 
-def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: GraphPlan, d: int, device) -> TrainPlan:
+def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: GraphPlan, d: int, device, exact: bool = False) -> TrainPlan:
+    """exact: `fwd` is a plan for the exact fp32 kernels (the range guard's fallback): the reversed graph is planned for them
+    too, and wide rows run the relation-stationary layer on fp32 MFMAs in both directions (GraphPlan.force_exact)."""
     if fwd.row_lo != 0 or (fwd.row_hi or fwd.N) != fwd.N or fwd.E != edge_index.size(1):
         raise NotImplementedError("training runs on single-GPU plans (every destination row, every edge)")
     ei = edge_index.to(device=device, dtype=torch.int64)
     rel = rel_ids.to(device=device, dtype=torch.int64).contiguous()
-    rev = build_plan(ei.flip(0).contiguous(), rel, fwd.unique_texts, fwd.N, d, device)
+    rev = build_plan(ei.flip(0).contiguous(), rel, fwd.unique_texts, fwd.N, d, device, exact=exact)
+    fwd.force_exact = rev.force_exact = exact
     by_dst = torch.sort(ei[1], stable=True).indices          # destinations ascending inside a relation: G / h_dst rows stay
     perm, goff = _native.group_edges(rel.index_select(0, by_dst), fwd.R)   # hot in L2 while a slice is contracted
     perm = by_dst.index_select(0, perm)
@@ -102,9 +105,14 @@ def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, fl
     if plan.block_nodes == 1 and _native.rs_supported(x.size(1)) and plan.E > 0:
         if plan.rs is None:
             plan.rs = build_rs(plan)
-        Y = plan.rs.scratch(plan.E, x.size(1), x.device)
-        _native.edge_transform_fwd(x, plan.rs, W, W_self, bias, Y)
-        _native.segment_tail_fwd(Y, plan.rs, None, None, None, 0.0, out, flags=flags)
+        old = _native._rs_exact_override
+        _native._rs_exact_override = old or plan.force_exact       # (the guard's fallback: pass 1 on fp32 MFMAs, forward and backward)
+        try:
+            Y = plan.rs.scratch(plan.E, x.size(1), x.device)
+            _native.edge_transform_fwd(x, plan.rs, W, W_self, bias, Y)
+            _native.segment_tail_fwd(Y, plan.rs, None, None, None, 0.0, out, flags=flags)
+        finally:
+            _native._rs_exact_override = old
         return out
     if residual is not None:                 # out = (the pass) + residual, added in the kernel's tail (GHF_FLAG_ADD_H): x_split names
         _native.message_layer_fwd(residual, plan, W, W_self, bias, plan.wlayout, None, None, 0.0, out,      # the gathered rows
@@ -195,9 +203,9 @@ class MessageLayerFn(torch.autograd.Function):
                 side = _side_stream(h.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
+                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact)
             else:
-                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R)
+                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact)
             d = h.size(1)
             dWm, dWs = dW[:, :d], dW[:, d:]
         else:
@@ -303,9 +311,14 @@ class InputProjFn(torch.autograd.Function):
         db = _native.colsum(dz)
         dx = None
         if ctx.needs_input_grad[0]:
-            if x.size(0) > 16 * 65535:
-                raise NotImplementedError("gradient with respect to node_features: at most 1,048,560 rows for now")
-            dx = _native.matmul_nn(dz, W.detach().contiguous())
+            # dz W in slabs of rows: one launch holds at most 65,535 x 16 rows of the result (a grid dimension)
+            Wc, slab = W.detach().contiguous(), 16 * 65535
+            if x.size(0) <= slab:
+                dx = _native.matmul_nn(dz, Wc)
+            else:
+                dx = torch.empty(x.size(0), Wc.size(1), dtype=torch.float32, device=x.device)
+                for a in range(0, x.size(0), slab):
+                    dx[a:a + slab] = _native.matmul_nn(dz[a:a + slab], Wc)
         return dx, dW, db, None
 
 

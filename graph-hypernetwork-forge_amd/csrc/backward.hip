@@ -776,9 +776,8 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
     // d % 128 == 0: two fp16 pieces on the 16-bit matrix pipe (edge_outer_h_kernel); GHF_EDGE_OUTER=exact keeps the fp32 MFMAs
     static const bool exact = getenv("GHF_EDGE_OUTER") && !strcmp(getenv("GHF_EDGE_OUTER"), "exact");
     unsigned* amax = (unsigned*)(partial_b + (size_t)nslices * D);     // two words behind the partial sums: max |h|, max |G|
-    const bool pieces = D == 128 && !exact;
+    const bool pieces = D == 128 && !exact && N > 0;      // (N <= 0: the caller asks for the exact fp32 chain, ghf.h)
     if (pieces) {
-        GHF_REQUIRE(N > 0, "edge_outer: N (rows of h and G) must be given");
         GHF_HIP_CHECK(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), stream));
         const unsigned ag = (unsigned)(cdiv(N * d, 256 * 16) < 2048 ? cdiv(N * d, 256 * 16) : 2048);
         absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h, G, N * d, amax);

@@ -128,6 +128,12 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_FLAGWAIT
 #define GHF_BX_FLAGWAIT 1      // 1: the staged rows are drained (lgkmcnt) before their flag is set (0 measured the same; kept conservative)
 #endif
+#ifndef GHF_BX_ILV
+#define GHF_BX_ILV 0          // 1: the previous chunk's rows are staged BETWEEN the k-steps of this chunk's first phase (a slice of the
+                              // ds_write per k-step, behind that k-step's MFMAs) instead of in front of them.  Measured slower
+                              // (same box: 3.18 vs 2.95-3.02 ms per C3 launch): the accumulators live through the phase (5 spilled
+                              // registers reloaded in the loop) and the helpers get the rows ~2,000 cycles later
+#endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
 #endif
@@ -526,9 +532,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // destination and second source of the adds relative to it (mode 0xa), base register v64.  M0 also holds the LDS
         // base of the wave's LDS-DMA instructions: saved and restored around the mode.  Steps past cnt read the row of
         // zeros into node 0 (no branch inside a step).
-        auto fold_rows = [&](int j, int rows, int lane) __attribute__((always_inline)) {
+        struct FoldPlan { int n0, n1, ra, cnt; };
+        // which of chunk j's rows are mine (one LDS round trip; taken BEFORE the wait for the staged rows: the descriptor has
+        // long been published)
+        auto fold_plan = [&](int j, int rows, int lane) __attribute__((always_inline)) -> FoldPlan {
             const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
-            const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
             int d0, d1;
             lds_ld_b32_x2(dd + 4 * lane, dd + 4 * (lane + 64 < CRP ? lane + 64 : CRP - 1), d0, d1);
             const int base = (int)node0 + hw * NPW;
@@ -537,21 +545,24 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             const unsigned long long q1 = __ballot(lane + 64 < rows && (unsigned)n1 < (unsigned)NPW);
             const int cnt = __builtin_popcountll(q0) + __builtin_popcountll(q1);
             const int ra = q0 ? (int)__builtin_ctzll(q0) : 64 + (q1 ? (int)__builtin_ctzll(q1) : 0);
+            return FoldPlan{n0, n1, ra, cnt};
+        };
+        auto fold_rows = [&](int j, const FoldPlan& fp, int lane) __attribute__((always_inline)) {
+            const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
+            const int ra = fp.ra, cnt = fp.cnt;
             const unsigned zrow = lds0 + ZERO_OFF + (unsigned)(PL * 4 * lane), lb = (unsigned)(PL * 4 * lane);
             typedef typename std::conditional<D == 128, f32x2, float>::type yv_t;
             // Eight rows per step, read as two batches of four: the second lands while the first is added (an LDS round trip is
             // ~250 cycles here, an indexed add ~12; more rows in flight and the register allocator starts to move the pinned
             // sums around).  Rows past the end read the row of zeros into node 0.
             constexpr int FB = 4;
-            int rwin = ra;                                               // first row of the window of 64 being folded
-            auto addr_of = [&](int r0, int i, int m) -> unsigned {       // LDS address of my row r0 + i's part (m: my rows in this window)
-                const int rr = rwin + r0 + i;
-                return r0 + i < m ? Y + (unsigned)rr * (D * 4) + (lb ^ (unsigned)(((rr >> 2) & 1) << 7)) : zrow;
-            };
-            auto issue = [&](yv_t (&y)[FB], int r0, int m) __attribute__((always_inline)) {
+            auto issue = [&](yv_t (&y)[FB], int r0) __attribute__((always_inline)) {
                 unsigned a[FB];
 #pragma unroll
-                for (int i = 0; i < FB; ++i) a[i] = addr_of(r0, i, m);
+                for (int i = 0; i < FB; ++i) {
+                    const int rr = ra + r0 + i;
+                    a[i] = r0 + i < cnt ? Y + (unsigned)rr * (D * 4) + (lb ^ (unsigned)(((rr >> 2) & 1) << 7)) : zrow;
+                }
                 if constexpr (D == 128)
                     asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7"
                                  : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
@@ -560,12 +571,16 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                                  : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
             };
             // the wait names the batch's registers: nothing may read them above it.  behind: the next batch is in flight
-            auto add_rows = [&](yv_t (&y)[FB], int nsel, int r0, int m, bool behind) __attribute__((always_inline)) {
+            auto add_rows = [&](yv_t (&y)[FB], int r0, bool behind) __attribute__((always_inline)) {
                 if (behind) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
                 int ix[FB];
 #pragma unroll
-                for (int i = 0; i < FB; ++i) ix[i] = PL * __builtin_amdgcn_readlane(nsel, r0 + i);      // (lanes past my rows hold node 0)
+                for (int i = 0; i < FB; ++i) {                           // the row's node: lane (row mod 64) of n0 or n1 (both read: no branch)
+                    const int rr = ra + r0 + i;
+                    const int a = __builtin_amdgcn_readlane(fp.n0, rr & 63), b = __builtin_amdgcn_readlane(fp.n1, rr & 63);
+                    ix[i] = r0 + i < cnt ? PL * (rr < 64 ? a : b) : 0;
+                }
                 int keep;
 #define BX_ROW128(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_pk_add_f32 v[64:65], %[y" #i "], v[64:65]\n\t"
 #define BX_ROW64(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_add_f32 v64, %[y" #i "], v64\n\t"
@@ -584,22 +599,14 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #undef BX_ROW64
 #undef BX_ROW_OPS
             };
-            for (int w0 = 0; w0 < cnt; w0 += 64) {                       // (one window unless more than 64 of the chunk's rows are mine)
-                const int m = cnt - w0 < 64 ? cnt - w0 : 64;
-                rwin = ra + w0;
-                // lane i: the node of my row w0 + i
-                const int r = ra + w0 + lane;
-                const int p0 = __builtin_amdgcn_ds_bpermute(4 * (r & 63), n0), p1 = __builtin_amdgcn_ds_bpermute(4 * (r & 63), n1);
-                const int nsel = lane < m ? (r < 64 ? p0 : p1) : 0;
-                // (straight-line per iteration: a batch in flight across a branch or the loop's back edge gets copied by the
-                // compiler — a phi — before its wait, i.e. read before it has landed)
-                for (int g = 0; g < m; g += 2 * FB) {
-                    yv_t ya[FB], yb[FB];
-                    issue(ya, g, m);
-                    issue(yb, g + FB, m);
-                    add_rows(ya, nsel, g, m, true);
-                    add_rows(yb, nsel, g + FB, m, false);
-                }
+            // (straight-line per iteration: a batch in flight across a branch or the loop's back edge gets copied by the
+            // compiler — a phi — before its wait, i.e. read before it has landed)
+            for (int g = 0; g < cnt; g += 2 * FB) {
+                yv_t ya[FB], yb[FB];
+                issue(ya, g);
+                issue(yb, g + FB);
+                add_rows(ya, g, true);
+                add_rows(yb, g + FB, false);
             }
         };
         // wait until all four words at `flags` have reached v (the waves of one role run the same program: short waits)
@@ -689,9 +696,10 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
+                const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
                 if (GHF_BX_DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
                 BX_STAMP(5);                               // (stamps: the wait for the staged rows)
-                fold_rows(k - 1, prev_rows, l0);
+                fold_rows(k - 1, fp, l0);
             }
             BX_LGKM0();
             if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 4 * hw, k + 1);   // this wave is through with Y(k-1)
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         __builtin_amdgcn_s_barrier();                      // ---- epilogue: the last chunk's rows
         if (nchunks > 0 && !(GHF_BXEXP & 8)) {
             const int le = opaque_lane(lane);
-            fold_rows(nchunks - 1, prev_rows, le);
+            fold_rows(nchunks - 1, fold_plan(nchunks - 1, prev_rows, le), le);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
         BX_LGKM0();
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // (always_inline: with two call sites and little work per instance — d = 64 — hipcc otherwise makes the stage a real
         // function, called through s_swappc with its captures in scratch: 10x the time)
         auto compute_stage = [&](auto mt_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
-                                 const float (&bias_v)[NTW]) __attribute__((always_inline)) {
+                                 const float (&bias_v)[NTW], auto&& between) __attribute__((always_inline)) {
             constexpr int MT = decltype(mt_c)::value;
             f32x4 part[MTC][NTW];
 #pragma unroll
@@ -844,6 +852,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 BX_STAMP(5);
+                between(j);
                 if (!(GHF_BXEXP & 1)) load_b_step(r_next, ph_next, j);
 #if GHF_BX_SCHED
                 __builtin_amdgcn_sched_barrier(0);
@@ -866,13 +875,13 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         };
         auto stage_for = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
-                             const float (&bias_v)[NTW]) __attribute__((always_inline)) {
+                             const float (&bias_v)[NTW], auto&& between) __attribute__((always_inline)) {
             // three instances: all tiles, one fewer, two fewer (shorter chunks — 7 % at C3 — run the last one: their dead
             // tiles cost MFMAs on stale rows that are never written)
             static_assert(MTC >= 3, "three compute_stage instances");
-            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
-            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
-            else compute_stage(std::integral_constant<int, MTC - 2>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v);
+            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between);
+            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between);
+            else compute_stage(std::integral_constant<int, MTC - 2>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between);
         };
         // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1) — with one
         // fragment per wave (d = 64), position 16tw + c16
@@ -895,6 +904,25 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
         };
 
+        // the same rows, slice j of KS (row tiles m = j, j + KS, ...; every tile, live or not: no branch — the helpers read the
+        // chunk's rows only)
+        auto write_rows_slice = [&](int j, unsigned ytile) __attribute__((always_inline)) {
+            const unsigned ybase = lds0 + ytile + yoff;
+#pragma unroll
+            for (int m = 0; m < MTC; ++m) {
+                if (m % KS != j) continue;
+                if (16 * m + 16 > CR && 16 * m + 4 * q >= CR) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (NTW == 2)
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ybase), "v"((f32x2){acc[m][0][s], acc[m][NTW - 1][s]}),
+                                     "n"((16 * m + s) * (D * 4)) : "memory");
+                    else
+                        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ybase), "v"(acc[m][0][s]), "n"((16 * m + s) * (D * 4)) : "memory");
+                }
+            }
+        };
+        auto nothing = [](int) {};
         const int ph_first = skip & 1;                     // the first live phase of a chunk
         BxChunk ch{0, 0, 1};
         i32x2 dn{0, 0};
@@ -922,7 +950,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             // GHF_BX_DEFER: the previous chunk's rows go to their staging tile (that chunk's destination-row tile) only now:
             // behind the barrier every consumer wave is through with that tile, so there is no hand-shake among the consumers,
             // and the accumulators are not needed before this chunk's first phase ends.  The helpers wait for the flag.
-            if (GHF_BX_DEFER && k > 0) {
+            constexpr bool ILV = GHF_BX_ILV && GHF_BX_DEFER && !(skip & 1) && !(GHF_BXEXP & 16);
+            if (GHF_BX_DEFER && k > 0 && !ILV) {
                 if (!(GHF_BXEXP & 16)) write_rows(mt_prev, P1_OFF + ((k - 1) & 1) * TILE);
 #if GHF_BX_FLAGWAIT
                 BX_LGKM0();
@@ -932,7 +961,19 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             const BxChunk nx = decode(dn);
             // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
-            if (!(skip & 1)) stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v);
+            if (!(skip & 1)) {
+                if (ILV && k > 0) {
+                    const unsigned ytile = P1_OFF + ((k - 1) & 1) * TILE;
+                    stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v,
+                              [&](int j) __attribute__((always_inline)) { write_rows_slice(j, ytile); });
+                } else {
+                    stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v, nothing);
+                }
+            }
+            if (ILV && k > 0) {                            // (the stage's unscale has not touched acc's OLD values before this point:
+                BX_LGKM0();                                //  compute_stage writes acc after its k-steps — the writes above read it before)
+                if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
+            }
             BX_STAMP(1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
@@ -951,7 +992,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){bias_v[t], bias_v[t], bias_v[t], bias_v[t]};
             }
-            if (!(skip & 2)) stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v);
+            if (!(skip & 2)) stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing);
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
             // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it

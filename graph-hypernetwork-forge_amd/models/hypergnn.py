@@ -250,15 +250,21 @@ class HyperGNN(nn.Module):
         """A dropout mask scaled by 1/(1-p), drawn with torch's generator as F.dropout does in the reference."""
         return draw_mask(shape, device, self.dropout)
 
-    def _forward_recorded(self, node_features: torch.Tensor, plan: GraphPlan, edge_index: torch.Tensor) -> torch.Tensor:
+    def _forward_recorded(self, node_features: torch.Tensor, plan: GraphPlan, edge_index: torch.Tensor, exact: bool = False) -> torch.Tensor:
         """The forward when gradients are required (reference: plain autograd, demo.py:79-101): the same kernels inside
         ``autograd`` Functions whose backward is C-ABI calls too.  The reversed-graph plan and the relation grouping the
-        backward needs are built once per plan."""
+        backward needs are built once per plan.  When the range guard fires, the forward is recorded again on the plan for the
+        exact fp32 kernels (exact=True; the first recording is dropped) — as the inference forward reruns, and as the
+        reference's plain fp32 autograd needs no such thing (hypergnn.py:202,228)."""
         from ..autograd import InputProjFn, MessageLayerFn, build_train_plan
         device = node_features.device
         if plan.train is None:
-            plan.train = build_train_plan(edge_index, plan.rel_ids, plan, self.hidden_dim, device)
-        guard = self._guarded(plan)
+            if exact:                      # (the exact plan was built from the first plan's sorted edges: take the triple from it)
+                src, dst, rel = plan.edge_arrays()
+                plan.train = build_train_plan(torch.stack([src, dst]), rel, plan, self.hidden_dim, device, exact=True)
+            else:
+                plan.train = build_train_plan(edge_index, plan.rel_ids, plan, self.hidden_dim, device)
+        guard = not exact and self._guarded(plan)
         if guard:
             flag = _native.range_flag(device)
             flag.zero_()
@@ -291,11 +297,12 @@ class HyperGNN(nn.Module):
                 W_msg, W_self, bias = gen.generate_with_grad(text_embs)
             drop = self._draw_mask(tuple(h.shape), device) if self._dropping() else None
             h = MessageLayerFn.apply(h, W_msg, W_self, bias, norm.weight, norm.bias, norm.eps, plan.train, drop)
-        if guard and int(flag.item()):
-            self.last_range_flags = int(flag.item())
-            raise RuntimeError("HyperGNN (training forward): a row of h or a relation's generated weights spans more dynamic range "
-                               "than the two-fp16-piece kernels hold (include/ghf.h: ghf_set_range_flag); train with "
-                               "GHF_KERNEL=pp (exact fp32 MFMA kernels) or normalise the node features")
+        if guard:
+            bits = int(flag.item())
+            self.last_range_flags = bits
+            if bits:
+                # (dropout: the masks of the second recording are fresh draws — one more forward's worth of the generator)
+                return self._forward_recorded(node_features, exact_plan(plan, self.hidden_dim), edge_index, exact=True)
         return h
 
     def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True, after=None):

@@ -245,6 +245,7 @@ class GraphPlan:
     train: Optional[object] = None  # autograd.TrainPlan, built by the first forward that records gradients
     rs: Optional[RsPlan] = None     # relation-stationary extras, built by the first wide-row forward
     exact: Optional["GraphPlan"] = None   # the same edges planned for the exact fp32 kernels (range guard fallback)
+    force_exact: bool = False             # recorded passes on this plan run the wide-row layer on fp32 MFMAs (autograd._message)
 
     def edge_arrays(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """(src, dst, relation id) int64 [E] of this plan's edges, decoded from the sorted arrays."""

@@ -287,8 +287,9 @@ int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, c
  * each relation.  workspace: nslices * (2*D*D + D) + 64 floats, D = min(d, 128).  Fixed summation order.  d = 64: exact fp32
  * (v_mfma_f32_16x16x4_f32); d % 128 == 0: two fp16 pieces per operand with ONE power-of-two scale per tensor (the largest
  * magnitude of h resp. G — found by the call — lifted into [2^13, 2^14)), three v_mfma_f32_16x16x32_f16 per product, fp32
- * accumulation: 22 significand bits relative to each tensor's largest entries (GHF_EDGE_OUTER=exact in the environment keeps
- * the fp32 chain). */
+ * accumulation: 22 significand bits relative to each tensor's largest entries.  N <= 0 (or GHF_EDGE_OUTER=exact in the
+ * environment) keeps the exact fp32 chain at every d: what the host mirror passes when a training step fell back to the exact
+ * kernels (range guard). */
 int ghf_edge_outer_supported(int d);
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                    const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N /* rows of h and G */, float* workspace,

@@ -34,7 +34,18 @@ for part in ("tcc", "fetch", "write", "sq"):
     for k, cs in acc.items():
         res.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in cs.items()})
         res[k]["_launches"] = max(res[k].get("_launches", 0), max(len(v) for v in cs.values()))
+import hashlib, os
+def digest(files):
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join("graph-hypernetwork-forge_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+srcs = {"message_kernel": ["message_bx.hip"], "c2_kernel": ["message_bx.hip", "message_pp.hip"], "c5_kernel": ["message_rs.hip"]}
 flat = {"_command": f"rocprofv3 --pmc <counters> -- {cmd} (one pass per counter group; per-launch means)"}
+for key, files in srcs.items():
+    if key in out:
+        flat["_source_sha256"] = digest(files)      # bench.py drops the traffic figure when the sources have moved on
+        flat["_sources"] = files
 if len(res) == 1:
     (k, v), = res.items()
     flat.update(v); flat["_kernel"] = k
