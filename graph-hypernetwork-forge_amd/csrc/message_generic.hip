@@ -159,10 +159,13 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t node0 = blk * BN;
     const int nrows_blk = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
-    const int vbase = ((int)blockIdx.y * (nslots - 1) + ((int)blockIdx.x - (i0 - base - lo))) * COMB_ROWS;
-    if (vbase >= nrows_blk) return;
-    const int nrows = nrows_blk < vbase + COMB_ROWS ? nrows_blk : vbase + COMB_ROWS;
-    for (int v = vbase + w; v < nrows; v += 4) {
+    // the block's groups of COMB_ROWS rows go round its (nslots - 1) x gridDim.y workgroups (a grid with one workgroup per
+    // group and column — 48 x 7 per block of eight items, six of seven returning at once — took 55 us per launch at BASELINE
+    // config 3: 15 k workgroups, each a chain of dependent loads; now 2.5 k)
+    const int wg = (int)blockIdx.y * (nslots - 1) + ((int)blockIdx.x - (i0 - base - lo)), nwg = (int)gridDim.y * (nslots - 1);
+    for (int vb = wg * COMB_ROWS; vb < nrows_blk; vb += nwg * COMB_ROWS) {
+    const int nrows = nrows_blk < vb + COMB_ROWS ? nrows_blk : vb + COMB_ROWS;
+    for (int v = vb + w; v < nrows; v += 4) {
         const int64_t node = node0 + v;
         const int deg = indeg[node];
         const float inv = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
             if (lane == 0) *(float*)((char*)h_split_out + (size_t)N * d * 4 + (size_t)node * 4) = pow2f(-sh);
         }
     }
+    }
 }
 
 int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
@@ -242,7 +246,9 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     const int64_t nblk = cdiv(a.rows, a.block_nodes), extra = a.n_items - nblk;     // items beyond one per block
     if (extra <= 0) return GHF_OK;
     GHF_REQUIRE(extra < (1ll << 31), "combine_split: too many work items");
-    const dim3 grid((unsigned)extra, (unsigned)cdiv(a.block_nodes, COMB_ROWS));
+    // gridDim.y x (a block's items - 1) workgroups share a block's row groups: eight rows of them cover a block of eight items
+    // (seven columns) in one pass, a block cut in two (one column) in six
+    const dim3 grid((unsigned)extra, (unsigned)(cdiv(a.block_nodes, COMB_ROWS) < 8 ? cdiv(a.block_nodes, COMB_ROWS) : 8));
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
                                                    a.ln_eps, a.N, a.d, a.block_nodes, blk0, (int)nblk, row_end, a.h_out, a.h_split_out, a.wlayout,
                                                    a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);

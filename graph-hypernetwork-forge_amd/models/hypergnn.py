@@ -305,7 +305,7 @@ class HyperGNN(nn.Module):
                 return self._forward_recorded(node_features, exact_plan(plan, self.hidden_dim), edge_index, exact=True)
         return h
 
-    def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True, after=None):
+    def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True, after=None, first=None):
         """([weights of layer l], [event l or None]): every layer's weight generation.  The generated weights depend on
         the relation strings only, so on large graphs their ~0.13 ms of small latency-bound kernels per layer are
         launched on a side stream and run in the shadow of the previous layers (C3: 13.0 -> 12.7 ms per forward); the
@@ -324,10 +324,16 @@ class HyperGNN(nn.Module):
             # (high-priority streams measured worse: 10.8 -> 11.6 ms per C3 forward)
             self._wg_stream = [torch.cuda.Stream(device=dev) for _ in range(nside)]
         weights, ready = [], []
+        nfirst = 0 if first is None else 1
+        if nfirst:                                             # layer 0's weights: already generated on the caller's stream
+            weights.append(first)
+            ready.append(None)
         try:
             for l, gen in enumerate(self.weight_generators):
+                if l < nfirst:
+                    continue
                 side = self._wg_stream[l % nside]
-                if l < nside:
+                if l < nside + nfirst:                         # a side stream's first use in this call
                     if after is not None:
                         side.wait_event(after)                            # an event recorded once text_embs was enqueued
                     else:
@@ -389,14 +395,17 @@ class HyperGNN(nn.Module):
         split = plan.wlayout in _native.SPLIT_LAYOUTS
         hs = _native.alloc_split(x.size(0), self.hidden_dim, plan.wlayout, device) if split else None
         hs_next = torch.empty_like(hs) if split else None
+        # Only layer 0's weights are needed before the first message launch.  Its generator — five small latency-bound
+        # kernels, ~0.15 ms alone — runs FIRST, on this stream: beside the input projection, which saturates HBM, the same
+        # kernels took 0.4 + 0.3 ms and the first message launch waited for them (kernel-trace timeline, round 3: 0.76 ms
+        # before the first message launch).  The later layers' generators run beside the projection on side streams as before.
+        side = plan.E >= self.SIDE_STREAM_MIN_EDGES
+        w0 = self.weight_generators[0].generate(text_embs, plan.wlayout) if side and os.environ.get("GHF_GEN0_FIRST", "1") != "0" else None
         h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach(), h_split=hs,
                                    split_layout=plan.wlayout if split else 0)
         h_next = torch.empty_like(h)
-        # (enqueued after the input projection: streams can share a hardware queue, and packets queue in host order; enqueued
-        # before it the forward measured the same, 10.87 ms at C3 — side by side the generators' kernels take 0.7 ms instead
-        # of 0.15 and still end with the projection)
-        weights, ready = self.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= self.SIDE_STREAM_MIN_EDGES,
-                                           after=te_done)
+        # (enqueued after the input projection: streams can share a hardware queue, and packets queue in host order)
+        weights, ready = self.generate_all(text_embs, plan.wlayout, side_stream=side, after=te_done, first=w0)
         lo, hi = plan.row_lo, (plan.row_hi or plan.N)
         last = len(self.weight_generators) - 1
         for l, norm in enumerate(self.layer_norms):
