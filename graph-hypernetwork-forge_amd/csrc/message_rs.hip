@@ -130,34 +130,45 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // KH = k per step: 32 (64-byte pieces of a row per visit; two workgroups per CU) or, for d % 256 == 0, 64 (whole 128-byte
 // lines, a half-row in four visits instead of eight; 129 KB of LDS, one workgroup per CU, the 16-byte granules of a row
 // XOR-swizzled by row & 7 so that a fragment read of 16 rows covers all banks).
-template <int KH>
-__global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
+// NCT = 128-column groups per workgroup (round 3): at d % 256 == 0 a workgroup of EIGHT waves takes a row tile's 128 rows
+// times 256 columns — waves 0-3 the first 128 columns, waves 4-7 the next, all eight reading the one A tile in LDS — so the
+// tile's rows are gathered once per 256 columns instead of once per 128: at d = 256 every gathered row is fetched once, not
+// twice (BASELINE config 5: 91 GB of 205 GB per layer were pass 1's fetches, profiles/r02_c5_kernel_pmc.json).
+template <int KH, int NCT>
+__global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
     const char* __restrict__ h_split, int64_t N, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
     const int64_t* __restrict__ ypos, const int64_t* __restrict__ slice_tab, const char* __restrict__ w2h, int R,
     const float* __restrict__ bias, const char* __restrict__ x_split, int64_t NX, const float* __restrict__ row_cnt,
     float* __restrict__ Y) {
-    constexpr int RS_KH = KH, GR = KH / 8, GPT = KH / 16;  // granules (8 fp16) per tile row; per thread, piece and step
+    constexpr int RS_KH = KH, GR = KH / 8, GPT = KH / 16;  // granules (8 fp16) per tile row; per thread, piece and step of B
+    constexpr int GPA = GPT / NCT, TPR = GR / GPA;         // A tile: granules per thread, threads per row (NCT x 256 threads, 128 rows)
+    static_assert(GPA >= 1 && (NCT == 1 || NCT == 2), "at most two column groups per workgroup");
     extern __shared__ __attribute__((aligned(16))) char rs_lds[];
     typedef _Float16 (*tile_t)[2][RS_TM][KH];              // [buffer][piece][row][k]
-    tile_t At = (tile_t)rs_lds, Bt = (tile_t)(rs_lds + (size_t)2 * 2 * RS_TM * KH * 2);
+    typedef _Float16 (*btile_t)[2][RS_TN * NCT][KH];
+    tile_t At = (tile_t)rs_lds;
+    btile_t Bt = (btile_t)(rs_lds + (size_t)2 * 2 * RS_TM * KH * 2);
     // per tile row: 2^-s of its source row, n 2^-s of its destination row, n — n = the number of edges the row stands for
     // (ghf.h: rows of pre-summed runs; 1 without them, and every product below is then what it was)
-    float (*rsc)[RS_TM] = (float (*)[RS_TM])(rs_lds + (size_t)2 * 2 * 2 * RS_TM * KH * 2);
+    float (*rsc)[RS_TM] = (float (*)[RS_TM])(rs_lds + (size_t)2 * 2 * (1 + NCT) * RS_TM * KH * 2);
     auto swz = [](int row, int g) { return KH == 64 ? (g ^ (row & 7)) : g; };
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int w = wv & 3, cg = wv >> 2;                     // row group (32 rows) and column group (128 columns) of this wave
     const int c16 = lane & 15, q = lane >> 4;
-    const unsigned ncol = (unsigned)d / RS_TN, tile = blockIdx.x / ncol;
+    const unsigned ncol = (unsigned)d / (RS_TN * NCT), tile = blockIdx.x / ncol;
     const int64_t r = slice_tab[3 * (size_t)tile], e0 = slice_tab[3 * (size_t)tile + 1], e1 = slice_tab[3 * (size_t)tile + 2];
-    const int n0 = (int)(blockIdx.x % ncol) * RS_TN;
+    const int n0 = (int)(blockIdx.x % ncol) * RS_TN * NCT;
     const size_t hrow = (size_t)4 * d;                     // bytes per split row
     const float* __restrict__ hscale = (const float*)(h_split + (size_t)N * hrow);
-    // staging map: thread t moves the 16-byte granules (row t/2, k 8 (GPT (t%2) + i) .. +7), i < GPT, of both pieces
-    const int srow = t >> 1, sg = GPT * (t & 1);
+    // staging map: thread t moves the 16-byte granules (row t/TPR, k 8 (GPA (t%TPR) + i) .. +7), i < GPA, of both pieces of
+    // the A tile, and (row t/2 of 128 NCT, k 8 (GPT (t%2) + i) .. +7), i < GPT, of the B tile
+    const int srow = t / TPR, sg = GPA * (t % TPR);
+    const int brow_i = t >> 1, sgb = GPT * (t & 1);
     int64_t e = e0 + srow;
     if (e >= e1) e = e1 - 1;                               // rows past the tile's end repeat its last edge (never stored)
     const int64_t su = src[e], sv = dst[e];               // su < 0: row ~su of x_split (the sum of a run's source rows)
     const char* __restrict__ urow = su >= 0 ? h_split + (size_t)su * hrow : x_split + (size_t)(~su) * hrow;
-    if ((t & 1) == 0) {
+    if ((t % TPR) == 0) {
         const float n = row_cnt ? row_cnt[e] : 1.0f;
         rsc[0][srow] = su >= 0 ? hscale[su] : ((const float*)(x_split + (size_t)NX * hrow))[~su];
         rsc[1][srow] = hscale[sv] * n;
@@ -168,29 +179,29 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
     // Four register sets: the rows of a step are requested three steps before they are written to LDS — this kernel's 293
     // registers leave one wave per SIMD, so a gather's latency (an HBM miss, ~2 us) has to be covered by this wave's own
     // MFMAs (768 cycles per step).
-    struct Stage { i32x4 a[2][GPT], b[2][GPT]; };          // [piece][i]
+    struct Stage { i32x4 a[2][GPA], b[2][GPT]; };          // [piece][i]
     Stage st[4];
     auto fetch = [&](int k0, Stage& S) {                   // k0: first contraction index of the step, in [0, 2d)
         const int half = k0 >= d;
         const int kk = half ? k0 - d : k0;
         const char* arow = half ? h_split + (size_t)sv * hrow : urow;
-        const char* brow = wr + ((size_t)half * 2 * d + (n0 + srow)) * (size_t)d * 2;
+        const char* brow = wr + ((size_t)half * 2 * d + (n0 + brow_i)) * (size_t)d * 2;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int i = 0; i < GPT; ++i) {
-                S.a[pl][i] = *(const i32x4*)(arow + (size_t)pl * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
-                S.b[pl][i] = *(const i32x4*)(brow + (size_t)pl * d * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
-            }
+            for (int i = 0; i < GPA; ++i) S.a[pl][i] = *(const i32x4*)(arow + (size_t)pl * d * 2 + (size_t)(kk + 8 * (sg + i)) * 2);
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) S.b[pl][i] = *(const i32x4*)(brow + (size_t)pl * d * d * 2 + (size_t)(kk + 8 * (sgb + i)) * 2);
+        }
     };
     auto commit = [&](int buf, const Stage& S) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int i = 0; i < GPT; ++i) {
-                *(i32x4*)&At[buf][pl][srow][8 * swz(srow, sg + i)] = S.a[pl][i];
-                *(i32x4*)&Bt[buf][pl][srow][8 * swz(srow, sg + i)] = S.b[pl][i];
-            }
+            for (int i = 0; i < GPA; ++i) *(i32x4*)&At[buf][pl][srow][8 * swz(srow, sg + i)] = S.a[pl][i];
+#pragma unroll
+            for (int i = 0; i < GPT; ++i) *(i32x4*)&Bt[buf][pl][brow_i][8 * swz(brow_i, sgb + i)] = S.b[pl][i];
+        }
     };
 
     f32x4 acc[2][8];                                       // [row tile][column tile]
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
                     for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
                         for (int pl = 0; pl < 2; ++pl) {
-                            const int row = 16 * (4 * ch + c4) + c16;
+                            const int row = RS_TN * cg + 16 * (4 * ch + c4) + c16;
                             b[c4][pl] = *(const i32x4*)&Bt[buf][pl][row][8 * swz(row, 4 * kk + q)];
                         }
 #pragma unroll
@@ -276,14 +287,14 @@ __global__ __launch_bounds__(256, KH == 32 ? 2 : 1) void edge_transform_h_kernel
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[ct][s] = bias[(size_t)r * d + n0 + 16 * ct + 4 * q + s];
+        for (int s = 0; s < 4; ++s) bv[ct][s] = bias[(size_t)r * d + n0 + RS_TN * cg + 16 * ct + 4 * q + s];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int row = 32 * w + 16 * rt + c16;
         const int64_t ee = e0 + row;
         if (ee < e1) {
             const float fv = rsc[1][row] * wscale, n = rsc[2][row];
-            float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + 4 * q;
+            float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + RS_TN * cg + 4 * q;
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 f32x4 o;
@@ -592,16 +603,24 @@ int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t
     // K-steps of 64 (whole 128-byte lines per visit, one workgroup per CU) measured 17.9 ms against 13.2 ms for K-steps of
     // 32 (two workgroups per CU) on one GPU's share of C5: occupancy beats line efficiency here.  GHF_RS_K=64 for A/B.
     static const bool k64 = getenv("GHF_RS_K") && atoi(getenv("GHF_RS_K")) == 64;
+    // d % 256 == 0: eight waves per workgroup, 256 columns per row tile (every gathered row fetched once per 256 columns);
+    // GHF_RS_NCT=1 keeps the four-wave workgroups for A/B
+    static const bool nct1 = getenv("GHF_RS_NCT") && atoi(getenv("GHF_RS_NCT")) == 1;
     if ((d % 256) == 0 && k64) {
         constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 64 * 2 + 3 * RS_TM * 4;
-        GHF_SET_MAX_LDS(edge_transform_h_kernel<64>, lds);
-        edge_transform_h_kernel<64><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
-                                                              (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
+        GHF_SET_MAX_LDS((edge_transform_h_kernel<64, 1>), lds);
+        edge_transform_h_kernel<64, 1><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
+                                                                 (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
+    } else if ((d % 256) == 0 && !nct1) {
+        constexpr size_t lds = (size_t)2 * 2 * 3 * RS_TM * 32 * 2 + 3 * RS_TM * 4;
+        GHF_SET_MAX_LDS((edge_transform_h_kernel<32, 2>), lds);
+        edge_transform_h_kernel<32, 2><<<grid / 2, 512, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
+                                                                     (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
     } else {
         constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 32 * 2 + 3 * RS_TM * 4;
-        GHF_SET_MAX_LDS(edge_transform_h_kernel<32>, lds);
-        edge_transform_h_kernel<32><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
-                                                              (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
+        GHF_SET_MAX_LDS((edge_transform_h_kernel<32, 1>), lds);
+        edge_transform_h_kernel<32, 1><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
+                                                                 (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
     }
     GHF_LAUNCH_CHECK();
     return GHF_OK;
