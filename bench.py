@@ -167,9 +167,9 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=10, help="timed launches of the message kernel for the roofline")
     ap.add_argument("--dist-mode", default=os.environ.get("GHF_DIST_MODE", "dst"), choices=["dst", "edges"],
                     help="N > 1: destination shards + all-gather (default) or edge-range shards + reduction (BASELINE config 4 as written)")
-    ap.add_argument("--exchange", default=os.environ.get("GHF_DIST_EXCHANGE", "auto"), choices=["auto", "allgather", "pairs"],
-                    help="N > 1, dst mode: all_gather_into_tensor per chunk, pairwise send/recv, or the faster of the two "
-                         "(timed during the warm-up)")
+    ap.add_argument("--exchange", default=os.environ.get("GHF_DIST_EXCHANGE", "auto"), choices=["auto", "allgather", "pairs", "sparse"],
+                    help="N > 1, dst mode: all_gather_into_tensor per chunk, pairwise send/recv, needed rows only (plan-time row "
+                         "lists, gather-pack / send / scatter), or the fastest of the three (timed during the warm-up)")
     ap.add_argument("--balance", default=os.environ.get("GHF_DIST_BALANCE", "rows"), choices=["rows", "edges"])
     ap.add_argument("--weak", action="store_true", help="N > 1: one full workload per GPU (nodes and edges scale with N)")
     args = ap.parse_args()
@@ -219,11 +219,13 @@ def main():
     runner = None
     exchange_pick = None
     if world > 1:
-        exch = args.exchange if args.dist_mode == "dst" and args.balance == "rows" else ("pairs" if args.balance == "edges" else "allgather")
+        os.environ.setdefault("GHF_DIST_ROW_STATS", "1")      # plan-time row lists also for the full exchanges: needed vs received rows
+        exch = args.exchange if args.dist_mode == "dst" and (args.balance == "rows" or args.exchange == "sparse") else (
+            "pairs" if args.balance == "edges" else "allgather")
         if exch == "auto":
             # both exchanges are built and timed for a few forwards; every rank takes the same decision (max over ranks)
             cand = {}
-            for name in ("allgather", "pairs"):
+            for name in ("allgather", "pairs", "sparse"):
                 r = ShardedHyperGNN(model, mode="dst", exchange=name, balance="rows")
                 with torch.no_grad():
                     r(x, edge_index, edge_texts)
@@ -289,7 +291,10 @@ def main():
         comp, exch_ms = timed("compute"), timed("exchange")
         step(); sync()
         nbytes = runner.stats.get("bytes_recv", 0.0)
-        mine = torch.tensor([comp, exch_ms, max(0.0, ms_step - comp), nbytes], device=dev, dtype=torch.float64)
+        sp = runner._sparse or {}
+        rows_needed = float(sp.get("rows_needed", -1))             # rows of other ranks this rank's edges read, per layer
+        rows_recv = rows_needed if runner.exchange == "sparse" else float(sp.get("rows_other", -1))   # (the last layer's rows travel whole)
+        mine = torch.tensor([comp, exch_ms, max(0.0, ms_step - comp), nbytes, rows_needed, rows_recv], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         links = max(1, world - 1)                         # xGMI: one link per peer
@@ -298,9 +303,12 @@ def main():
             "exchange_candidates_ms": exchange_pick,
             "per_rank": [{"rank": r, "compute_ms": float(v[0]), "exchange_ms": float(v[1]), "exposed_exchange_ms": float(v[2]),
                           "bytes_received_per_forward": float(v[3]),
+                          "rows_needed_per_layer": int(v[4]), "rows_received_per_layer": int(v[5]),
                           "gb_per_s_per_link": float(v[3]) / links / max(float(v[1]), 1e-9) / 1e6} for r, v in enumerate(allr)],
             "note": "compute_ms / exchange_ms: the forward with the exchange / the kernels switched off (3 runs each); "
-                    "exposed = ms_per_step - compute_ms; per-link rate = bytes received / (world - 1) links / exchange_ms"}
+                    "exposed = ms_per_step - compute_ms; per-link rate = bytes received / (world - 1) links / exchange_ms; "
+                    "rows_needed = distinct source rows of this rank's in-edges that other ranks own (the exchange's floor per "
+                    "layer), rows_received = what this exchange delivers per inner layer (-1: edge-range mode)"}
 
     line = None
     if rank == 0:

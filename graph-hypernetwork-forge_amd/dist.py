@@ -14,7 +14,11 @@ Two partitions of the path, behind one interface (`ShardedHyperGNN`, SURVEY.md Â
   numbers of in-edges (``balance="edges"``: power-law graphs, BASELINE config 5).
   The exchange is either ``all_gather_into_tensor`` per chunk (RCCL picks ring or direct) or ``exchange="pairs"``: every
   rank sends its slot straight to each peer (batched send/recv) â€” xGMI is a full mesh of point-to-point links, and a
-  pairwise exchange uses all seven of a GPU's links at once where a ring is bound by one.
+  pairwise exchange uses all seven of a GPU's links at once where a ring is bound by one.  ``exchange="sparse"`` sends
+  only what the receiver reads: a rank gathers the SOURCE rows of its in-edges, so at plan time every rank tells each peer
+  which of that peer's rows it needs (per chunk), and a layer's exchange is gather-pack -> pairwise send/recv -> scatter
+  of exactly those rows (a uniform random shard of C3 at 8 ranks reads 71 % of the rows; graphs with locality far
+  fewer).  The last layer's rows travel whole: every rank returns the full [N, d].
 * ``mode="edges"`` â€” BASELINE.json's north-star split (config 4): every rank takes a contiguous range of the EDGE list
   (balanced by construction), computes raw partial sums for all rows (GHF_FLAG_RAW_SUM), the partial sums are reduced
   (reduce-scatter; all-reduce where the backend has no reduce-scatter), each rank divides by the global in-degree and runs
@@ -135,6 +139,10 @@ class NativeOps:
         return build_plan(edge_index, rel_ids, unique, N, d, device,
                           force_generic=_native.prefer_rs(d, len(unique)) and "edge_range" not in shard, **shard)
 
+    def plan_sources(self, plan) -> torch.Tensor:
+        """Source node of every edge this rank's plan holds (what its kernels gather from h)."""
+        return plan.edge_arrays()[0]
+
     def text_embs(self, model, unique: Sequence[str], device) -> torch.Tensor:
         return model.text_encoder(unique, device)
 
@@ -207,8 +215,8 @@ class NativeOps:
 class ShardedHyperGNN:
     """Runs ``HyperGNN.forward`` across the ranks of a process group; every rank returns the full [N, d].
 
-    mode: "dst" | "edges"; exchange: "allgather" | "pairs" (dst mode); balance: "rows" | "edges" (dst mode; "edges" implies
-    the pairwise exchange, whose messages may differ in size).  Defaults from GHF_DIST_MODE / GHF_DIST_EXCHANGE /
+    mode: "dst" | "edges"; exchange: "allgather" | "pairs" | "sparse" (dst mode); balance: "rows" | "edges" (dst mode; "edges"
+    implies a pairwise exchange, whose messages may differ in size).  Defaults from GHF_DIST_MODE / GHF_DIST_EXCHANGE /
     GHF_DIST_BALANCE / GHF_DIST_CHUNKS."""
 
     def __init__(self, model, group: Optional[dist.ProcessGroup] = None, ops=None, chunks: Optional[int] = None,
@@ -222,9 +230,9 @@ class ShardedHyperGNN:
         self.mode = mode or os.environ.get("GHF_DIST_MODE", "dst")
         self.balance = balance or os.environ.get("GHF_DIST_BALANCE", "rows")
         self.exchange = exchange or os.environ.get("GHF_DIST_EXCHANGE", "allgather")
-        if self.mode not in ("dst", "edges") or self.balance not in ("rows", "edges") or self.exchange not in ("allgather", "pairs"):
+        if self.mode not in ("dst", "edges") or self.balance not in ("rows", "edges") or self.exchange not in ("allgather", "pairs", "sparse"):
             raise ValueError(f"ShardedHyperGNN: mode={self.mode!r} balance={self.balance!r} exchange={self.exchange!r}")
-        if self.balance == "edges":
+        if self.balance == "edges" and self.exchange == "allgather":
             self.exchange = "pairs"
         self.backend = dist.get_backend(group)
         # what the backend offers is decided once, here â€” not by catching errors around a collective, which would hide real
@@ -237,6 +245,8 @@ class ShardedHyperGNN:
         self._spec: Optional[ShardSpec] = None
         self._inv = None
         self.last_range_flags = 0                                        # what the range guard saw in the last forward (OR over ranks)
+        self._full_rows = False
+        self._sparse: Optional[dict] = None
         self._comm_stream = None
         self._compute_streams: List = []
 
@@ -245,7 +255,9 @@ class ShardedHyperGNN:
         """Make every rank's slot of chunk c of a row-indexed buffer visible on every rank."""
         if self.profile == "compute":
             return
-        if self.exchange == "pairs" or not spec.uniform:
+        if self.exchange == "sparse" and not self._full_rows:
+            return self._gather_sparse(buf, spec, c)
+        if self.exchange in ("pairs", "sparse") or not spec.uniform:
             return self._gather_pairs(buf, spec, c)
         lo, hi = spec.chunk_rows(c)
         if hi > buf.size(0):                                   # a buffer of exactly N rows: the chunk that reaches past N
@@ -301,11 +313,76 @@ class ShardedHyperGNN:
             for lo, hi, t in recvs:
                 buf[lo:hi].copy_(t)
 
-    def _run_chunked(self, bufs, spec: ShardSpec, compute_rows) -> None:
+    def _gather_sparse(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
+        """Chunk c, needed rows only: to every peer the rows of my slot it asked for at plan time (packed), from every peer
+        the rows of its slot that my edges read, scattered to their places.  Rows nobody on this rank reads stay stale."""
+        send_idx, recv_idx = self._sparse["send"][c], self._sparse["recv"][c]
+        bounce = buf.is_cuda and self.backend == "gloo"
+        ops, recvs, keep = [], [], []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if send_idx[p].numel():
+                packed = buf.index_select(0, send_idx[p])
+                packed = packed.cpu() if bounce else packed
+                keep.append(packed)
+                ops.append(dist.P2POp(dist.isend, packed, p, group=self.group))
+            if recv_idx[p].numel():
+                t = torch.empty((recv_idx[p].numel(),) + tuple(buf.shape[1:]), dtype=buf.dtype, device="cpu" if bounce else buf.device)
+                ops.append(dist.P2POp(dist.irecv, t, p, group=self.group))
+                recvs.append((recv_idx[p], t))
+                self.stats["bytes_recv"] = self.stats.get("bytes_recv", 0.0) + t.numel() * t.element_size()
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for idx, t in recvs:
+            buf.index_copy_(0, idx, t.to(buf.device) if bounce else t)
+
+    def _plan_sparse(self, plan: GraphPlan, spec: ShardSpec, device) -> dict:
+        """Who needs which rows: recv[c][p] = the rows of rank p's slot of chunk c that this rank's edges read (sorted row ids,
+        on the device), send[c][q] = the rows of MY slot of chunk c that rank q reads.  One exchange of index lists per
+        plan (host tensors through the group: counts by all_gather, lists pairwise)."""
+        G, C, me = self.world, spec.chunks, self.rank
+        if plan.E > 0:
+            need = torch.unique(self.ops.plan_sources(plan))
+            slot = torch.bucketize(need, torch.tensor(spec.bounds[1:], dtype=torch.int64, device=need.device), right=True)
+            need, slot = need.cpu(), slot.cpu()
+        else:
+            need = slot = torch.zeros(0, dtype=torch.int64)
+        want = [[need[(slot == c * G + p)] if p != me else need[:0] for p in range(G)] for c in range(C)]
+        cnt = torch.tensor([[want[c][p].numel() for p in range(G)] for c in range(C)], dtype=torch.int64)
+        allc = [torch.zeros_like(cnt) for _ in range(G)]
+        dist.all_gather(allc, cnt, group=self.group)                    # allc[q][c][p]: rows q needs from p in chunk c
+        ops, bufs = [], {}
+        for p in range(G):
+            if p == me:
+                continue
+            out = torch.cat([want[c][p] for c in range(C)]) if C else need[:0]
+            if out.numel():
+                ops.append(dist.P2POp(dist.isend, out, p, group=self.group))
+            n_in = int(allc[p][:, me].sum())
+            if n_in:
+                bufs[p] = torch.empty(n_in, dtype=torch.int64)
+                ops.append(dist.P2POp(dist.irecv, bufs[p], p, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        send = [[need[:0].to(device)] * G for _ in range(C)]
+        for p, t in bufs.items():
+            parts = torch.split(t, [int(allc[p][c, me]) for c in range(C)])
+            for c in range(C):
+                send[c] = list(send[c])
+                send[c][p] = parts[c].to(device)
+        recv = [[want[c][p].to(device) for p in range(G)] for c in range(C)]
+        owned = sum(hi - lo for lo, hi in spec.owned())
+        return {"send": send, "recv": recv, "rows_needed": int(cnt.sum()), "rows_other": int(spec.N - owned)}
+
+    def _run_chunked(self, bufs, spec: ShardSpec, compute_rows, full_rows: bool = False) -> None:
         """compute_rows(lo, hi) fills my rows of a chunk in every buffer of `bufs`; the chunk's exchange overlaps the next
         chunk's compute."""
         bufs = [bufs] if isinstance(bufs, torch.Tensor) else list(bufs)
         buf = bufs[0]
+        self._full_rows = full_rows                            # (sparse exchange: this step's rows travel whole)
         on_gpu = buf.is_cuda
         skip_compute = self.profile == "exchange"
         if on_gpu:
@@ -376,11 +453,14 @@ class ShardedHyperGNN:
                     block_edges = torch.bincount(torch.div(edge_index[1], bn, rounding_mode="floor"), minlength=nb).cpu().tolist()
                 spec = shard_spec(N, bn, self.world, self.rank, self.chunks, block_edges)
                 plan = self.ops.build_plan(edge_index, torch.from_numpy(ids), unique, N, d, device, **spec.owner_arg(), **kw)
-            hit = (plan, spec, inv, (edge_index, edge_texts))
+            sparse = None
+            if self.mode == "dst" and self.world > 1 and (self.exchange == "sparse" or os.environ.get("GHF_DIST_ROW_STATS") == "1"):
+                sparse = self._plan_sparse(plan, spec, device)
+            hit = (plan, spec, inv, (edge_index, edge_texts), sparse)
             while len(self._plans) >= 4:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = hit
-        self._plan, self._spec, self._inv = hit[0], hit[1], hit[2]
+        self._plan, self._spec, self._inv, self._sparse = hit[0], hit[1], hit[2], hit[4]
         return self._plan
 
     # -- forward ----------------------------------------------------------------------------------------
@@ -443,7 +523,8 @@ class ShardedHyperGNN:
             self.ops.layer_begin(model, l, weights, src[:N], plan)
             src_split = self.ops.split_rows(plan, src[:N])          # all rows are in place after the previous exchange
             self._run_chunked(dst, spec, lambda lo, hi: self.ops.layer_rows(model, l, weights, src[:N], src_split, plan,
-                                                                            dst[:N], lo, hi))
+                                                                            dst[:N], lo, hi),
+                              full_rows=l == model.num_layers - 1)
             h, h_next = h_next, h
         return h[:N]
 
@@ -471,7 +552,7 @@ class ShardedHyperGNN:
             out_split = None if l == last else hs_next
             self._run_chunked(dst if l == last else ops.split_parts(plan, hs_next, N, d), spec,
                               lambda lo, hi: ops.layer_rows(model, l, weights, src[:N], src_split, plan, dst[:N], lo, hi,
-                                                            h_split_out=out_split))
+                                                            h_split_out=out_split), full_rows=l == last)
             h, h_next = h_next, h
             hs, hs_next = hs_next, hs
         return h[:N]

@@ -44,6 +44,9 @@ class OracleOps:
             keep = (edge_index[1] // S) % G == g                     # a rank owns the in-edges of its rows
         return SimpleNamespace(unique_texts=unique, ei=edge_index[:, keep], rel=rel_ids[keep], N=N, wlayout=0, E=int(keep.sum()))
 
+    def plan_sources(self, plan):
+        return plan.ei[0]
+
     @staticmethod
     def _params(model):
         return {k: v.detach() for k, v in model.state_dict().items()}
@@ -87,8 +90,11 @@ class OracleOps:
         p = self._params(model)
         if self.split:                                               # other ranks' rows exist in the split form only
             N, d = h.shape
-            assert bool((h_split[N * d:] == 1.0).all()), "a row scale did not arrive"
+            # every row this rank's edges read must have arrived, scale included (the sparse exchange sends no others)
+            read = torch.unique(plan.ei[0])
+            assert bool((h_split[N * d:][read] == 1.0).all()), "a row scale did not arrive"
             full = h_split[: N * d].view(N, d)
+            assert bool(torch.isfinite(full[read]).all()), "a row this rank reads did not arrive"
             assert torch.equal(full[lo:hi], h[lo:hi])
             h = full
         agg = O.message_passing_factorised(h, plan.ei, plan.rel, w["W_msg"], w["W_self"], w["bias"])
@@ -161,7 +167,11 @@ def test_sharded_forward_equals_reference(golden_dir, world, case_name, bn, chun
     (3, "g3_mid32", 64, 3, True, dict(balance="edges")), (2, "g2_toy", 8, 4, False, dict(balance="edges")),
     (3, "g2_chain", 4, 2, True, dict(balance="edges")),
     (2, "g3_mid32", 64, 1, False, dict(mode="edges")), (3, "g3_mid32", 216, 1, False, dict(mode="edges")),
-    (3, "g2_toy", 8, 1, False, dict(mode="edges"))])
+    (3, "g2_toy", 8, 1, False, dict(mode="edges")),
+    # needed rows only: plan-time row lists per (chunk, peer), gather-pack -> send/recv -> scatter; the last layer whole
+    (2, "g3_mid32", 64, 3, False, dict(exchange="sparse")), (3, "g3_mid32", 216, 4, True, dict(exchange="sparse")),
+    (3, "g2_chain", 4, 2, True, dict(exchange="sparse")), (3, "g3_mid32", 64, 3, True, dict(exchange="sparse", balance="edges")),
+    (2, "g2_toy", 8, 4, False, dict(exchange="sparse"))])
 def test_sharded_variants_equal_reference(golden_dir, world, case_name, bn, chunks, split, kw):
     """The pairwise exchange (every rank sends its slot straight to each peer), slots balanced by in-edge count (unequal
     sizes, pairwise exchange), and the north-star split — edge-range shards, raw partial sums reduced across ranks, tail on

@@ -1558,6 +1558,9 @@ def _run_ranks(world, name, kw):
     # every rank sends its slot straight to each peer; slots of about equal in-edge counts on a power-law graph
     ("g6_c3", 2, dict(exchange="pairs")), ("g5_c2", 3, dict(exchange="pairs")),
     ("g6_c3_powerlaw", 3, dict(balance="edges")), ("g6_c3_powerlaw", 2, dict(balance="edges")), ("g7_c5", 2, dict(balance="edges")),
+    # needed rows only (plan-time row lists per chunk and peer; gather-pack, send/recv, scatter); the last layer whole
+    ("g6_c3", 2, dict(exchange="sparse")), ("g5_c2", 3, dict(exchange="sparse")), ("g6_c3_powerlaw", 3, dict(exchange="sparse", balance="edges")),
+    ("g7_c5", 2, dict(exchange="sparse")),
 ])
 def test_sharded_forward_multi_rank_on_one_gpu(golden_dir, name, world, kw):
     """The whole multi-rank product path — ownership-filtered (or edge-range) plans, chunked launches, per-layer exchange
