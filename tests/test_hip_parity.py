@@ -83,6 +83,43 @@ def test_input_projection_and_its_fused_split(N, F, d):
     assert torch.equal(_native.input_proj_fwd(x, W, b), h0)
 
 
+@pytest.mark.parametrize("N,F,d", [(20000, 128, 128), (5000, 64, 64), (3001, 32, 128), (70000, 96, 64)])
+def test_input_projection_on_two_fp16_pieces(N, F, d, monkeypatch):
+    """Callers on the two-piece path (they ask for the SPLIT2H rows) get the projection on fp16 pieces too (round 3): within the
+    fp32 tolerance of relu(x W^T + b) (reference hypergnn.py:261), its pieces = ghf_split_rows of its output bit for bit, rows
+    with a wide dynamic range raise the guard, and GHF_INPUT_PROJ=exact / callers without split rows keep the fp32 MFMAs."""
+    x = synth.normal(6, "x", (N, F))
+    x[::7] *= 37.0                                                   # rows of different magnitudes: one power of two per row
+    x[5] = 0.0
+    x = torch.from_numpy(x).to(DEV)
+    W = torch.from_numpy(synth.normal(6, "W", (d, F), std=0.2)).to(DEV)
+    b = torch.from_numpy(synth.normal(6, "b", (d,), std=0.5)).to(DEV)
+    flag = _native.range_flag(DEV)
+    flag.zero_()
+    hs = _native.alloc_split(N, d, _native.WLAYOUT_SPLIT2H, DEV)
+    h0 = _native.input_proj_fwd(x, W, b, h_split=hs, split_layout=_native.WLAYOUT_SPLIT2H)
+    xd, Wd, bd = x.cpu().double(), W.cpu().double(), b.cpu().double()
+    ref = torch.relu(xd @ Wd.t() + bd)
+    # the bound of include/ghf.h: 4 * 2^-22 * sum_k |x_k w_k| per output (rows scaled by 37 have sums of ~600: an element that
+    # cancels to 0.07 carries the sum's rounding, in fp32 arithmetic as here) — and the usual relative L2
+    bound = 4.0 * 2.0 ** -22 * (xd.abs() @ Wd.abs().t() + bd.abs()) + 1e-7
+    err = (h0.cpu().double() - ref).abs()
+    assert bool((err <= bound).all()), f"input projection on two fp16 pieces: worst error / bound {float((err / bound).max()):.3f}"
+    assert float(torch.linalg.norm(h0.cpu().double() - ref) / torch.linalg.norm(ref)) < 1e-6
+    assert torch.equal(hs, _native.split_rows(h0, _native.WLAYOUT_SPLIT2H))
+    assert int(flag.item()) == 0
+    exact = _native.input_proj_fwd(x, W, b)
+    assert bool(((exact.cpu().double() - ref).abs() <= bound).all()), "fp32 projection"
+    assert not torch.equal(exact, h0), "the two paths are different kernels (this test would be vacuous otherwise)"
+    # a row whose small entries lie 2^30 below its largest: flagged
+    x2 = x.clone()
+    x2[11, 0] = 3.0e9
+    flag.zero_()
+    _native.input_proj_fwd(x2, W, b, h_split=hs, split_layout=_native.WLAYOUT_SPLIT2H)
+    assert int(flag.item()) & _native.RANGE_ROWS
+    flag.zero_()
+
+
 def test_score_triple_and_fused_edge_scores():
     """reference :304-318 and its call form score_triple(embs[src], embs[dst]) (demo.py:90-94)."""
     model = HyperGNN(text_dim=16, node_feat_dim=8, hidden_dim=128, num_layers=1).to(DEV).eval().requires_grad_(False)
