@@ -13,6 +13,8 @@
 // for the hidden sizes it is built for.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace ghf {
 
 constexpr int GEN_MAX_D = 1024;
@@ -248,7 +250,8 @@ int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
     GHF_REQUIRE(extra < (1ll << 31), "combine_split: too many work items");
     // gridDim.y x (a block's items - 1) workgroups share a block's row groups: eight rows of them cover a block of eight items
     // (seven columns) in one pass, a block cut in two (one column) in six
-    const dim3 grid((unsigned)extra, (unsigned)(cdiv(a.block_nodes, COMB_ROWS) < 8 ? cdiv(a.block_nodes, COMB_ROWS) : 8));
+    static const int ymax = getenv("GHF_COMB_Y") ? atoi(getenv("GHF_COMB_Y")) : 8;
+    const dim3 grid((unsigned)extra, (unsigned)(cdiv(a.block_nodes, COMB_ROWS) < ymax ? cdiv(a.block_nodes, COMB_ROWS) : ymax));
     combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
                                                    a.ln_eps, a.N, a.d, a.block_nodes, blk0, (int)nblk, row_end, a.h_out, a.h_split_out, a.wlayout,
                                                    a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);

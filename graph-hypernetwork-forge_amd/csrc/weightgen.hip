@@ -194,6 +194,56 @@ __global__ __launch_bounds__(256) void wg_out_mfma_kernel(const float* __restric
     }
 }
 
+// The three heads' last layers in ONE launch (natural order outputs; blockIdx.y = head): on the critical path of a forward
+// the generator is a chain of small latency-bound kernels, and three of its five were these (round 3: 0.18 -> 0.11 ms).
+struct OutHeads {
+    const float* z[3];
+    const float* W3[3];
+    const float* b3[3];
+    const float* log_scale[3];
+    float* out[3];
+    int n_out[3];
+    size_t rstride[3];
+};
+__global__ __launch_bounds__(256) void wg_out_mfma3_kernel(OutHeads H, int R, int Hl) {
+    const int head = blockIdx.y;
+    const float* __restrict__ z = H.z[head];
+    const float* __restrict__ W3 = H.W3[head];
+    const float* __restrict__ b3 = H.b3[head];
+    float* __restrict__ out = H.out[head];
+    const int n_out = H.n_out[head];
+    const size_t rstride = H.rstride[head];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int mt = blockIdx.x * 4 + wv;
+    if (mt * 16 >= n_out) return;
+    const int n_a = 16 * mt + c16;
+    const bool a_ok = n_a < n_out;
+    const float* __restrict__ arow = W3 + (size_t)(a_ok ? n_a : 0) * Hl + 4 * q;
+    const float scale = expf(H.log_scale[head][0]);
+    const int NJ = Hl >> 4;
+    for (int r0 = 0; r0 < R; r0 += 16) {
+        const int rc = r0 + c16;
+        const bool b_ok = rc < R;
+        const float* __restrict__ brow = z + (size_t)(b_ok ? rc : 0) * Hl + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 a = *(const f32x4*)(arow + 16 * j);
+            f32x4 b = *(const f32x4*)(brow + 16 * j);
+            if (!a_ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!b_ok) b = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+        }
+        if (!b_ok) continue;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int n = 16 * mt + 4 * q + s;
+            if (n < n_out) out[(size_t)rc * rstride + n] = (acc[s] + b3[n]) * scale;
+        }
+    }
+}
+
 // GHF_WLAYOUT_SPLIT2H, second step.  W holds [R][2d][d] fp32 ([W_msg[r]; W_self[r]] row-major); one workgroup per
 // relation pulls its matrix into LDS, finds the largest magnitude, and rewrites the same bytes as fp16 B fragments
 //   Wh[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8],  piece 0 = fp16(w 2^s), piece 1 = fp16(w 2^s - piece 0)
@@ -362,6 +412,34 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
 
     const int Hl = num_hidden ? Hh : T;
     const int n_mat = d_in * d_out;
+    // natural-order outputs (NATURAL, and SPLIT2H before its packing step): all three heads in one launch when the MFMA tile
+    // applies to each of them
+    if (layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_SPLIT2H) {
+        OutHeads H;
+        bool ok = (Hl % 16) == 0;
+        for (int head = 0; head < 3; ++head) {
+            H.z[head] = hidden_ws + (size_t)head * R * Hl;
+            H.W3[head] = P.w[head][num_hidden];
+            H.b3[head] = P.b[head][num_hidden];
+            H.log_scale[head] = log_scales[head];
+            H.n_out[head] = head == 2 ? d_out : n_mat;
+            H.rstride[head] = (layout == GHF_WLAYOUT_SPLIT2H && head != 2) ? (size_t)2 * n_mat : (size_t)H.n_out[head];
+            H.out[head] = head == 2 ? bias : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg + (size_t)head * n_mat : (head == 0 ? W_msg : W_self));
+            ok = ok && ((((uintptr_t)H.W3[head] | (uintptr_t)H.z[head]) & 15) == 0);
+        }
+        if (ok) {
+            const int mtiles = (n_mat + 15) / 16;
+            wg_out_mfma3_kernel<<<dim3((mtiles + 3) / 4, 3), 256, 0, stream>>>(H, R, Hl);
+            GHF_LAUNCH_CHECK();
+            if (layout == GHF_WLAYOUT_SPLIT2H) {
+                const size_t lds = (size_t)2 * n_mat * 4;
+                GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
+                wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out, range_flag_ptr());
+                GHF_LAUNCH_CHECK();
+            }
+            return GHF_OK;
+        }
+    }
     for (int head = 0; head < 3; ++head) {
         const float* z = hidden_ws + (size_t)head * R * Hl;
         const float* W3 = P.w[head][num_hidden];
