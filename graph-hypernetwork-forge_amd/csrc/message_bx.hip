@@ -134,6 +134,11 @@ __device__ __forceinline__ int opaque_lane(int lane) {
                               // (same box: 3.18 vs 2.95-3.02 ms per C3 launch): the accumulators live through the phase (5 spilled
                               // registers reloaded in the loop) and the helpers get the rows ~2,000 cycles later
 #endif
+#ifndef GHF_BX_PRE
+#define GHF_BX_PRE 1          // bit 0 / bit 1 (first / second phase): a stage's first A fragments are requested AHEAD of the stage — the first phase's behind the barrier,
+                              // in front of the deferred staging writes; the second phase's in front of the first phase's unscale —
+                              // so that their LDS round trip (~370 cycles per stage: tools/stamps_bx.py, "stage prologue") is covered
+#endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
 #endif
@@ -796,9 +801,22 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         // (a uniform branch per (k-step, tile) position cost the MFMA stream a fetch bubble each)
         // (always_inline: with two call sites and little work per instance — d = 64 — hipcc otherwise makes the stage a real
         // function, called through s_swappc with its captures in scratch: 10x the time)
-        auto compute_stage = [&](auto mt_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
-                                 const float (&bias_v)[NTW], auto&& between) __attribute__((always_inline)) {
+        constexpr int AD = GHF_BX_AD;
+        static_assert(AD <= MTC - 2, "the prefetched positions are row tiles 0 .. AD-1 of the first k-step in every instance");
+        i32x4 apre[AD][NPL];                               // GHF_BX_PRE: the fragments of a stage's first AD positions
+        auto lda_from = [&](const char* Abuf, int j, int m, i32x4 (&dst)[NPL]) __attribute__((always_inline)) {
+            const char* src = Abuf + arow + (((4 * j + q) ^ akey(c16)) << 4) + m * 16 * ROWB;     // akey(16 m + c16) = akey(c16)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) dst[pl] = *(const i32x4*)(src + pl * PLANE);
+        };
+        auto prefetch_a = [&](const char* Abuf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < AD; ++p) lda_from(Abuf, 0, p, apre[p]);
+        };
+        auto compute_stage = [&](auto mt_c, auto pre_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+                                 const float (&bias_v)[NTW], auto&& between, auto&& after_k) __attribute__((always_inline)) {
             constexpr int MT = decltype(mt_c)::value;
+            constexpr bool PRE = decltype(pre_c)::value;
             f32x4 part[MTC][NTW];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -808,15 +826,17 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             // A fragments of (k-step, tile) positions p .. p + AD: with the helpers' DMA writes and fold reads on the LDS a read
             // takes ~250 cycles, a position's six MFMAs 96 (tools/stamps_bx.py: two positions ahead left the stage
             // latency-bound)
-            constexpr int AD = GHF_BX_AD;
             i32x4 a[AD + 1][NPL];
-            auto lda = [&](int j, int m, i32x4 (&dst)[NPL]) {
-                const char* src = Abuf + arow + (((4 * j + q) ^ akey(c16)) << 4) + m * 16 * ROWB;     // akey(16 m + c16) = akey(c16)
+            auto lda = [&](int j, int m, i32x4 (&dst)[NPL]) { lda_from(Abuf, j, m, dst); };
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) dst[pl] = *(const i32x4*)(src + pl * PLANE);
-            };
+            for (int p = 0; p < AD && p < KS * MT; ++p) {
+                if constexpr (PRE) {
 #pragma unroll
-            for (int p = 0; p < AD && p < KS * MT; ++p) lda(p / MT, p % MT, a[p]);
+                    for (int pl = 0; pl < NPL; ++pl) a[p][pl] = apre[p][pl];
+                } else {
+                    lda(p / MT, p % MT, a[p]);
+                }
+            }
             BX_STAMP(4);
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
@@ -859,6 +879,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #endif
                 BX_STAMP(7);
             }
+            after_k();                                      // (GHF_BX_PRE: the next stage's first fragments, requested before the unscale)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -874,14 +895,14 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         };
-        auto stage_for = [&](int mt, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
-                             const float (&bias_v)[NTW], auto&& between) __attribute__((always_inline)) {
+        auto stage_for = [&](int mt, auto pre_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+                             const float (&bias_v)[NTW], auto&& between, auto&& after_k) __attribute__((always_inline)) {
             // three instances: all tiles, one fewer, two fewer (shorter chunks — 7 % at C3 — run the last one: their dead
             // tiles cost MFMAs on stale rows that are never written)
             static_assert(MTC >= 3, "three compute_stage instances");
-            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between);
-            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between);
-            else compute_stage(std::integral_constant<int, MTC - 2>{}, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between);
+            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, pre_c, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
+            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, pre_c, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
+            else compute_stage(std::integral_constant<int, MTC - 2>{}, pre_c, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
         };
         // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1) — with one
         // fragment per wave (d = 64), position 16tw + c16
@@ -947,6 +968,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             const int* meta = (const int*)(smem + meta_off(k));
             __syncthreads();                               // ---- chunk k
             BX_STAMP(0);
+            constexpr bool PRE_OK = skip == 0 && !YT && GHF_BX_LATE;
+            constexpr bool PRE0 = (GHF_BX_PRE & 1) && PRE_OK, PRE1 = (GHF_BX_PRE & 2) && PRE_OK;      // first / second phase
+            using pre0_t = std::integral_constant<bool, PRE0>;
+            using pre1_t = std::integral_constant<bool, PRE1>;
+            if (PRE0) prefetch_a(smem + P0_OFF + (k & 1) * TILE);      // (chunk k's source rows landed before the barrier)
             // GHF_BX_DEFER: the previous chunk's rows go to their staging tile (that chunk's destination-row tile) only now:
             // behind the barrier every consumer wave is through with that tile, so there is no hand-shake among the consumers,
             // and the accumulators are not needed before this chunk's first phase ends.  The helpers wait for the flag.
@@ -961,13 +987,31 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             const BxChunk nx = decode(dn);
             // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
+            // behind the first phase's k-steps: this chunk's destination rows have landed (helpers' flags) -> the second phase's
+            // first fragments are requested before the first phase's unscale
+            auto wait_landed = [&]() __attribute__((always_inline)) {
+                for (;;) {
+                    i32x4 f;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 32) : "memory");
+                    const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
+                    if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            };
+            auto next_pre = [&]() __attribute__((always_inline)) {
+                if (PRE1) {
+                    wait_landed();
+                    prefetch_a(smem + P1_OFF + (k & 1) * TILE);
+                }
+            };
+            auto no_after = []() {};
             if (!(skip & 1)) {
                 if (ILV && k > 0) {
                     const unsigned ytile = P1_OFF + ((k - 1) & 1) * TILE;
-                    stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v,
-                              [&](int j) __attribute__((always_inline)) { write_rows_slice(j, ytile); });
+                    stage_for(mt, pre0_t{}, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v,
+                              [&](int j) __attribute__((always_inline)) { write_rows_slice(j, ytile); }, next_pre);
                 } else {
-                    stage_for(mt, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v, nothing);
+                    stage_for(mt, pre0_t{}, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v, nothing, next_pre);
                 }
             }
             if (ILV && k > 0) {                            // (the stage's unscale has not touched acc's OLD values before this point:
@@ -977,22 +1021,14 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             BX_STAMP(1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
-            if (GHF_BX_LATE && !(skip & 2) && !YT) {       // the destination-row tile of this chunk has landed (helpers' flags)
-                for (;;) {
-                    i32x4 f;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 32) : "memory");
-                    const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
-                    if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
+            if (GHF_BX_LATE && !(skip & 2) && !YT && !PRE1) wait_landed();   // the destination-row tile of this chunk has landed (helpers' flags)
             if (skip & 1) {                                // no source phase ran: the destination phase adds to the bias
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){bias_v[t], bias_v[t], bias_v[t], bias_v[t]};
             }
-            if (!(skip & 2)) stage_for(mt, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing);
+            if (!(skip & 2)) stage_for(mt, pre1_t{}, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing, no_after);
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
             // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it
