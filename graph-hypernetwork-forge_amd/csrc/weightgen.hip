@@ -452,14 +452,14 @@ int launch_weightgen(const float* text_emb, const float* const* head_params, con
         float* out = head == 2 ? bias : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg + (size_t)head * n_mat
                                          : (layout != GHF_WLAYOUT_NATURAL ? W_msg : (head == 0 ? W_msg : W_self)));
         const int klayout = nat ? GHF_WLAYOUT_NATURAL : layout;
-        const bool mfma_ok = head != 2 && (Hl % 16) == 0 &&
-                             ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
-        if (mfma_ok && layout == GHF_WLAYOUT_FRAG16) {
+        // (the bias head runs the same MFMA chain in every layout: its values do not depend on the layout asked for)
+        const bool mfma_ok = (Hl % 16) == 0 && ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
+        if (mfma_ok && layout == GHF_WLAYOUT_FRAG16 && head != 2) {
             const int mtiles = n_mat / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
                 z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
         } else if (mfma_ok) {
-            const int mtiles = (n_mat + 15) / 16;
+            const int mtiles = (n_out + 15) / 16;
             wg_out_mfma_kernel<GHF_WLAYOUT_NATURAL><<<(mtiles + 3) / 4, 256, 0, stream>>>(
                 z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
         } else {
