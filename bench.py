@@ -62,7 +62,7 @@ def layer_flops(N, E, R, d):
 
 def kern_name(plan, d):
     from graph_hypernetwork_forge_amd import _native
-    return {_native.WLAYOUT_SPLIT2H: "message_hx_kernel" if plan.block_nodes == 216 else "message_bx_kernel"}.get(
+    return {_native.WLAYOUT_SPLIT2H: "message_bx_kernel"}.get(
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
@@ -381,7 +381,7 @@ def main():
         if wide:
             kern = ("run_rows_kernel + " if plan.rs is not None and plan.rs.run_start is not None else "") + \
                    "edge_transform%s_kernel + segment_tail_kernel<%d> (one layer, cutting rows and weights included)" % ("" if _native.rs_exact() else "_h", d // 64)
-        # matrix work the kernel issues per algorithmic flop: 3 fp16 products (bx, hx), 1 fp32 (pp)
+        # matrix work the kernel issues per algorithmic flop: 3 fp16 products (bx), 1 fp32 (pp)
         prod, mpeak = {_native.WLAYOUT_SPLIT2H: (3, F16_MATRIX_PEAK_TF)}.get(
             plan.wlayout, (1, FP32_MATRIX_PEAK_TF))
         if wide and not _native.rs_exact():

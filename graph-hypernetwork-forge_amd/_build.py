@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(CSRC, "_obj" + ("_" + VARIANT if VARIANT else ""))
 LIB_PATH = os.path.join(PKG_DIR, "libghf_hip" + ("_" + VARIANT if VARIANT else "") + ".so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["capi.hip", "plan.hip", "text_encoder.hip", "score.hip", "backward.hip", "weightgen.hip", "input_proj.hip", "message_generic.hip", "message_pp.hip", "message_hx.hip", "message_bx.hip", "message_rs.hip"]
+SOURCES = ["capi.hip", "plan.hip", "text_encoder.hip", "score.hip", "backward.hip", "weightgen.hip", "input_proj.hip", "message_generic.hip", "message_pp.hip", "message_bx.hip", "message_rs.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ghf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 import re as _re
@@ -29,9 +29,6 @@ if VARIANT == "ablate":
 _b = _re.search(r"baux(\d+)", VARIANT)
 if _b:
     FLAGS.append("-DGHF_B_AUX=" + _b.group(1))
-_t = _re.search(r"opt(\d+)", VARIANT)
-if _t:
-    FLAGS.append("-DGHF_OPT=" + _t.group(1))          # A/B switches of message_hx.hip (see GHF_OPT there)
 _x = _re.search(r"bxexp(\d+)", VARIANT)
 if _x:
     FLAGS.append("-DGHF_BXEXP=" + _x.group(1))         # compile-time ablations of message_bx.hip (timing only)
@@ -50,13 +47,6 @@ if "eopin" in VARIANT:
     FLAGS.append("-DGHF_EO_PIN")
 if "eoslow" in VARIANT:
     FLAGS.append("-DGHF_EO_SLOW_FRAG")                  # debug: edge_outer_h fragments read element by element
-_m = _re.search(r"(?<!bx)exp(\d+)", VARIANT)
-if _m:
-    # compile-time ablations of message_hx.hip (GHF_EXP bit mask; wrong results, timing only): unlike the run-time flags
-    # of the "ablate" build they add no branches, so what is left runs exactly as in the product ("stampsexp<mask>"
-    # combines them with the stamps)
-    FLAGS.append("-DGHF_EXP=" + _m.group(1))
-
 
 def hipcc_path() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):

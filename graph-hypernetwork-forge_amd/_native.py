@@ -426,7 +426,7 @@ def prefer_rs(d: int, R: int) -> bool:
     kernel re-streams a relation's weights per (block, relation) chunk, so its time grows with R while the
     relation-stationary layer's does not (tools/relation_sweep_rs.py, C3-sized graph, ms per layer, message_bx / relation-
     stationary: R = 64: 3.5 / 5.8, 96: 4.1 / 5.6, 128: 4.8 / 5.7, 192: 9.2 / 5.9, 256: 11.0 / 5.7)."""
-    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("bx", "hx", "pp"):
+    if not rs_supported(d) or os.environ.get("GHF_KERNEL") in ("bx", "pp"):
         return False
     return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
 

@@ -43,7 +43,7 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
     if (!block_nodes || !wlayout || !chunk_rows || !split_chunks) return set_err(GHF_EINVAL, "message_config: null output pointer");
     int bn = 1, cr = 0, sc = 0;
     // GHF_KERNEL selects the d = 128 kernel for A/B runs: "bx" (default) = two fp16 pieces, three products, block sums in
-    // registers (message_bx.hip); "hx" = the same contraction with the block sums in LDS (message_hx.hip); "pp" = exact fp32,
+    // registers (message_bx.hip; round 1's LDS-sum variant message_hx.hip was removed in round 3); "pp" = exact fp32,
     // v_mfma_f32_16x16x4_f32 (message_pp.hip: also what the range guard falls back to)
     // "rs" / "rs32" / "generic": a CSR plan also where a destination-block kernel exists (A/B of the relation-stationary
     // layer at d = 128)
@@ -54,11 +54,6 @@ int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, i
         *chunk_rows = 0;
         *split_chunks = 0;
     } else if ((!kv || !strcmp(kv, "bx")) && message_bx_config(d, &bn, &cr, &sc)) {
-        *block_nodes = bn;
-        *wlayout = GHF_WLAYOUT_SPLIT2H;
-        *chunk_rows = cr;
-        *split_chunks = sc;
-    } else if ((!kv || !strcmp(kv, "hx")) && message_hx_config(d, &bn, &cr, &sc)) {
         *block_nodes = bn;
         *wlayout = GHF_WLAYOUT_SPLIT2H;
         *chunk_rows = cr;
@@ -182,8 +177,10 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     if (agg_out && !ghf_message_side_output_supported(d, block_nodes, wlayout))
         return set_err(GHF_EUNSUPPORTED, "message_layer_fwd: no side output from the kernel for d=%d, block_nodes=%d, layout %d", d, block_nodes, wlayout);
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);
-    if (wlayout == GHF_WLAYOUT_SPLIT2H && message_bx_owns(d, block_nodes)) return launch_message_bx(a, (hipStream_t)stream);
-    if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_message_hx(a, (hipStream_t)stream);
+    if (wlayout == GHF_WLAYOUT_SPLIT2H) {
+        GHF_REQUIRE(message_bx_owns(d, block_nodes), "message_layer_fwd: no SPLIT2H kernel for d=%d with blocks of %d nodes", d, block_nodes);
+        return launch_message_bx(a, (hipStream_t)stream);
+    }
     GHF_REQUIRE(wlayout == GHF_WLAYOUT_FRAG16, "message_layer_fwd: unknown weight layout %d", wlayout);
     return launch_message_pp(a, (hipStream_t)stream);
 }

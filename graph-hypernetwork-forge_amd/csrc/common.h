@@ -175,8 +175,6 @@ struct MsgArgs {
     float* agg_out;              // optional side output: the aggregate before the tail (ghf.h)
 };
 int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream);
-int launch_message_hx(const MsgArgs& a, hipStream_t stream);       // fp16 two-piece contraction (d = 128), SPLIT2H weights
-bool message_hx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 int launch_message_bx(const MsgArgs& a, hipStream_t stream);       // the same contraction, block sums in registers (message_bx.hip)
 bool message_bx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks);
 bool message_bx_owns(int d, int block_nodes);                      // whether a SPLIT2H plan of this geometry is message_bx's

@@ -1111,6 +1111,43 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     return GHF_OK;
 }
 
+// ghf_split_rows, SPLIT2H: one wave per row — the row's largest magnitude picks the power of two
+__global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restrict__ h, int64_t N, int64_t row0, int64_t rows,
+                                                           int d, char* __restrict__ out, int32_t* __restrict__ range_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    const int64_t row = row0 + i;
+    const float* __restrict__ src = h + row * d;
+    float mx = 0.f;
+    for (int k = lane; k < d; k += 64) mx = fmaxf(mx, fabsf(src[k]));
+    const int sh = split2h_shift(wave_absmax(mx));
+    const float up = pow2f(sh);
+    _Float16* __restrict__ dst = (_Float16*)(out + row * (4 * (int64_t)d));
+    int tiny = 0, nz = 0;
+    for (int k = lane; k < d; k += 64) {
+        _Float16 hi, lo;
+        const float xs = src[k] * up;
+        split2h(xs, hi, lo);
+        dst[k] = hi;
+        dst[d + k] = lo;
+        tiny += __popcll(__ballot(range_tiny(xs)));
+        nz += __popcll(__ballot(xs != 0.f));
+    }
+    if (lane == 0) {
+        *(float*)(out + N * (4 * (int64_t)d) + row * 4) = pow2f(-sh);
+        range_raise(range_flag, GHF_RANGE_ROWS, tiny, nz);
+    }
+}
+
+int launch_split2h_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows, void* h_split, hipStream_t stream) {
+    if (rows <= 0) return GHF_OK;
+    GHF_REQUIRE(cdiv(rows, 4) < (1ll << 31), "split_rows: too many rows per launch");
+    split2h_rows_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, stream>>>(h, N, row0, rows, d, (char*)h_split, range_flag_ptr());
+    GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
 bool message_bx_config(int d, int* block_nodes, int* chunk_rows, int* split_chunks) {
     if (d != 128 && d != 64) return false;
     *block_nodes = d == 128 ? BxCfg<128>::BN : BxCfg<64>::BN;

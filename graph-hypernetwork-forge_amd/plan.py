@@ -98,7 +98,7 @@ CSR_CONFIG = (1, _native.WLAYOUT_NATURAL, 0, 0)      # no destination blocks: re
 
 def block_kernel_max_nodes(d: int, wlayout: int) -> int:
     """How many rows of h a destination-block kernel can address: their gathers use 32-bit byte offsets into the row table
-    (csrc/message_bx.hip / message_hx.hip: N (4d + 4) bytes of split rows and scales; message_pp.hip: N 4d bytes of fp32
+    (csrc/message_bx.hip: N (4d + 4) bytes of split rows and scales; message_pp.hip: N 4d bytes of fp32
     rows), 4 GiB less the page the kernels point dead rows at.  d = 128: 8.3 M rows."""
     per_row = 4 * d + (4 if wlayout in _native.SPLIT_LAYOUTS else 0)
     return ((1 << 32) - 4096) // per_row

@@ -42,8 +42,6 @@ def test_native_library_is_loaded():
     assert _native.message_config(64) == (256, _native.WLAYOUT_SPLIT2H, 112, 128)
     assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
     try:
-        os.environ["GHF_KERNEL"] = "hx"
-        assert _native.message_config(128) == (216, _native.WLAYOUT_SPLIT2H, 48, 128)
         os.environ["GHF_KERNEL"] = "pp"
         assert _native.message_config(128) == (216, _native.WLAYOUT_FRAG16, 48, 128)
     finally:
@@ -317,15 +315,15 @@ def _pack_weights(plan, Wm, Ws):
 
 
 def _skip_unless_kernel_exists(kernel, d):
-    """d = 128: all three kernels; d = 64: bx and pp; other sizes have one kernel (run once, under "bx")."""
-    if kernel not in {128: ("hx", "bx", "pp"), 64: ("bx", "pp")}.get(d, ("bx",)):
+    """d = 128 and 64: bx and pp; other sizes have one kernel (run once, under "bx")."""
+    if kernel not in {128: ("bx", "pp"), 64: ("bx", "pp")}.get(d, ("bx",)):
         pytest.skip(f"no {kernel} kernel for d = {d}")
 
 
-@pytest.fixture(params=["hx", "bx", "pp"])
+@pytest.fixture(params=["bx", "pp"])
 def kernel(request, monkeypatch):
-    """The d = 128 message kernels: two fp16 pieces with the block sums in registers (bx, the default) or in LDS (hx), and
-    the exact v_mfma_f32_16x16x4_f32 kernel the range guard falls back to (pp)."""
+    """The d = 128 / 64 message kernels: two fp16 pieces with the block sums in registers (bx, the default) and the exact
+    v_mfma_f32_16x16x4_f32 kernel the range guard falls back to (pp)."""
     monkeypatch.setenv("GHF_KERNEL", request.param)
     return request.param
 

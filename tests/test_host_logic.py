@@ -34,13 +34,10 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
     assert (bn.value, wl.value, cr.value, sc.value) == (384, 3, 76, 128)      # two fp16 pieces, block sums in registers (default)
     try:
-        os.environ["GHF_KERNEL"] = "hx"
-        assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
-        assert (bn.value, wl.value, cr.value, sc.value) == (216, 3, 48, 128)  # the same contraction, block sums in LDS
         os.environ["GHF_KERNEL"] = "pp"
         assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
         assert (bn.value, wl.value, cr.value, sc.value) == (216, 1, 48, 128)  # fp32 MFMA contraction
-        os.environ["GHF_KERNEL"] = "sx"                                        # (a retired name: the default)
+        os.environ["GHF_KERNEL"] = "hx"                                        # (a retired name — round 1's LDS-sum kernel: the exact one)
         assert lib.ghf_message_config(128, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
         assert (bn.value, wl.value) == (216, 1)
     finally:

@@ -1,5 +1,5 @@
 """Small dense cases of the block kernels (D=128 default; D=64) against a float64 evaluation, with WHERE the wrong rows sit (position of
-their edges in the chunk, relation, destination).  GHF_KERNEL picks the kernel (bx / hx)."""
+their edges in the chunk, relation, destination).  GHF_KERNEL picks the kernel (bx / pp)."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graph_hypernetwork_forge_amd import _native

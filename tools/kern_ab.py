@@ -1,4 +1,4 @@
-"""A/B of the d = 128 message kernels on one box: one C3-sized layer per GHF_KERNEL value (KERNELS=hx,bx), ms per launch
+"""A/B of the d = 128 message kernels on one box: one C3-sized layer per GHF_KERNEL value (KERNELS=pp,bx), ms per launch
 by HIP events, and the largest difference of each kernel's output from the first one's."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ Wm = torch.randn(R, d, d, generator=gen, device=dev) * 0.05
 Ws = torch.randn(R, d, d, generator=gen, device=dev) * 0.05
 b = torch.randn(R, d, generator=gen, device=dev); g = torch.ones(d, device=dev); bt = torch.zeros(d, device=dev)
 ref = None
-for kern in os.environ.get("KERNELS", "hx,bx").split(","):
+for kern in os.environ.get("KERNELS", "pp,bx").split(","):
     os.environ["GHF_KERNEL"] = kern
     plan = build_plan(torch.from_numpy(ei).to(dev), torch.from_numpy(rel).to(dev), [""] * R, N, d, dev)
     W = _native.weights_pack(Wm, Ws, False, R, d, plan.wlayout)

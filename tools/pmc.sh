@@ -2,12 +2,12 @@
 # Collect PMC counters of one kernel with rocprofv3, one pass per counter group (run on the GPU box):
 #   tools/pmc.sh <out-prefix> <kernel-name-regex> -- <program> [args...]
 #     -> gpurun_out/<out-prefix>_{tcc,fetch,write,sq}.csv + <out-prefix>_pmc.json (per-launch means of the matching kernel)
-#   default program: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5, kernel message_(bx|hx|pp)_kernel
+#   default program: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5, kernel message_(bx|pp)_kernel
 # Counters only (--pmc): never combined with the trace domains on this pool.  FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 counts
 # a wide streaming read at half its bytes (MI355X_MICROARCH.md): readers double FETCH_SIZE.
 set -e
 cd "$(dirname "$0")/.."
-out=${1:-pmc}; kern=${2:-'message_(bx|hx|pp)_kernel'}
+out=${1:-pmc}; kern=${2:-'message_(bx|pp)_kernel'}
 if [ "$3" = "--" ]; then shift 3; else set -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel-reps 5; fi
 export TMPDIR=/tmp
 mkdir -p gpurun_out

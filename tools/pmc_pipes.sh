@@ -26,7 +26,7 @@ for g in "${groups[@]}"; do
   echo "pass $i: $g"
   timeout -k 5 150 rocprofv3 --pmc $g -d gpurun_out/_pp_$i -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --kernel-reps 3 > gpurun_out/_pp_$i.log 2>&1 || { echo "group $i failed"; grep -m1 -i "error code" gpurun_out/_pp_$i.log; }
   f=$(find gpurun_out/_pp_$i -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E 'Counter_Name|message_(bx|hx)_kernel' "$f" >> gpurun_out/${out}_pipes.csv
+  [ -n "$f" ] && grep -E 'Counter_Name|message_bx_kernel' "$f" >> gpurun_out/${out}_pipes.csv
   i=$((i+1))
 done
 python3 - "$out" <<'PY'

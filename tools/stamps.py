@@ -37,21 +37,17 @@ for _ in range(2):
 torch.cuda.synchronize()
 nb = min(8192, -(-N // plan.block_nodes))
 buf = np.zeros(8192 * 8 * 8, dtype=np.uint64)
-# message_bx.hip has its own reader (tools/stamps_bx.py); here: the LDS-sum kernel (GHF_KERNEL=hx) and the exact fp32 one
-hx = plan.wlayout in _native.SPLIT_LAYOUTS
-if hx and plan.block_nodes == 384:
-    raise SystemExit("the default d = 128 kernel is stamped by tools/stamps_bx.py; set GHF_KERNEL=hx or pp for this tool")
-fn = getattr(lib, "ghf_debug_read_stamps_hx" if hx else "ghf_debug_read_stamps_pp")
+# message_bx.hip has its own reader (tools/stamps_bx.py); here: the exact fp32 kernel (GHF_KERNEL=pp)
+if plan.wlayout in _native.SPLIT_LAYOUTS:
+    raise SystemExit("the default kernels are stamped by tools/stamps_bx.py; set GHF_KERNEL=pp for this tool")
+fn = lib.ghf_debug_read_stamps_pp
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert fn(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(8192, 8, 8)[:nb].astype(np.float64)
 tot = st.sum(axis=2)
-if hx:   # producer / consumer kernel (message_hx.hip): waves 0-3 consume, 4-7 produce
-    names = ["barrier wait", "consumer: unscale+rest", "producer: gather issue", "producer: commit", "consumer: bias+scatter", "consumer: k-step 0 (issue-stamped)", "drain+tail", "consumer: k-steps 1-3 (issue-stamped)"]
-else:    # ping-pong kernel (message_pp.hip)
-    names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: gather issue"]
+names = ["barrier wait", "mfma interval", "prep: rest of issue", "prep: scatter", "prep: mem wait", "prep: words+shuffles", "drain+tail", "prep: gather issue"]   # ping-pong kernel (message_pp.hip)
 print(f"blocks={nb} mean cycles per wave = {tot.mean():.0f}")
-g0, g1 = ("consumers", "producers") if hx else ("team0", "team1")
+g0, g1 = "team0", "team1"
 for i, n in enumerate(names[:8]):
     print(f"  {n:24s} {100 * st[:, :, i].sum() / tot.sum():6.2f} %   mean {st[:, :, i].mean():10.0f}   {g0} {st[:, :4, i].mean():10.0f}  {g1} {st[:, 4:, i].mean():10.0f}")
