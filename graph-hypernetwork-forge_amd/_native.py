@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 GHF_FLAG_ZERO_SRC = 4
@@ -46,6 +46,8 @@ SIGNATURES = {
                               _vp, _vp]),
     "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                  _vp, _vp, _vp, _vp, _vp]),
+    "ghf_weightgen_fwd_batched": (_i32, [_i32, _vp, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+                                         C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "ghf_text_encode_fwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ghf_message_layer_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _i32,
@@ -308,6 +310,37 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
                                  _ptr(None if hidden_drop is None else _req(hidden_drop, torch.float32, "hidden_drop")), _stream()),
            "ghf_weightgen_fwd")
     return W_msg, W_self, bias
+
+
+def weightgen_fwd_batched(text_emb: torch.Tensor, head_params: Sequence[Sequence[torch.Tensor]], log_scales: Sequence[Sequence[torch.Tensor]],
+                          T: int, Hh: int, num_hidden: int, d_in: int, d_out: int, layout: int):
+    """All L generators of a model in one launch sequence (include/ghf.h: ghf_weightgen_fwd_batched): head_params[g] /
+    log_scales[g] as weightgen_fwd takes them; returns [(W_msg or Wfrag, W_self or None, bias)] per generator."""
+    lib = load()
+    x = _req(text_emb, torch.float32, "text_emb")
+    R, dev, L = x.size(0), x.device, len(head_params)
+    keep = [_req(p, torch.float32, "weight-generator parameter") for g in head_params for p in g]
+    arr = (_vp * len(keep))(*[p.data_ptr() for p in keep])
+    ls_keep = [_req(t, torch.float32, "log_scale") for g in log_scales for t in g]
+    if len(ls_keep) != 3 * L:
+        raise ValueError("weightgen_fwd_batched: three log-scale tensors per generator expected")
+    ls = (_vp * len(ls_keep))(*[t.data_ptr() for t in ls_keep])
+    hidden_ws = torch.empty(L * 3 * 2 * R * max(Hh, T, 1), dtype=torch.float32, device=dev)
+    outs = []
+    for _ in range(L):
+        if layout != WLAYOUT_NATURAL:
+            W_msg = torch.empty(lib.ghf_weights_bytes(R, d_in, d_out, layout) // 4, dtype=torch.float32, device=dev)
+            W_self = None
+        else:
+            W_msg = torch.empty(R, d_in, d_out, dtype=torch.float32, device=dev)
+            W_self = torch.empty(R, d_in, d_out, dtype=torch.float32, device=dev)
+        outs.append((W_msg, W_self, torch.empty(R, d_out, dtype=torch.float32, device=dev)))
+    wm = (_vp * L)(*[o[0].data_ptr() for o in outs])
+    wsf = (_vp * L)(*[(None if o[1] is None else o[1].data_ptr()) for o in outs])
+    bs = (_vp * L)(*[o[2].data_ptr() for o in outs])
+    _check(lib.ghf_weightgen_fwd_batched(L, _ptr(x), arr, ls, R, T, Hh, num_hidden, d_in, d_out, layout, _ptr(hidden_ws),
+                                         wm, wsf, bs, _stream()), "ghf_weightgen_fwd_batched")
+    return outs
 
 
 def text_encode_fwd(ids: torch.Tensor, lens: torch.Tensor, char_emb: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -106,6 +106,14 @@ int ghf_weightgen_fwd(const float* text_emb, const float* const* head_params, co
                             hidden_ws, W_msg, W_self, bias, hidden_drop, (hipStream_t)stream);
 }
 
+int ghf_weightgen_fwd_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,
+                              int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout, float* hidden_ws,
+                              float* const* W_msg, float* const* W_self, float* const* bias, void* stream) {
+    GHF_REQUIRE(text_emb && head_params && log_scales && hidden_ws && W_msg && bias, "weightgen_fwd_batched: null pointer argument");
+    return launch_weightgen_batched(L, text_emb, head_params, log_scales, R, T, Hh, num_hidden, d_in, d_out, layout, hidden_ws,
+                                    W_msg, W_self, bias, nullptr, (hipStream_t)stream);
+}
+
 int ghf_text_encode_fwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
                         const float* W, const float* b, int T, float* out, void* stream) {
     GHF_REQUIRE(ids && lens && char_emb && W && b && out, "text_encode_fwd: null pointer argument");

@@ -154,6 +154,10 @@ constexpr int32_t SRC_MASK = (1 << SRC_BITS) - 1;
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream);
+int launch_weightgen_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,
+                             int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
+                             float* hidden_ws, float* const* W_msg, float* const* W_self, float* const* bias,
+                             const float* hidden_drop, hipStream_t stream);
 
 int launch_score_pairs(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,
                        int64_t n, int d, float* scores, hipStream_t stream);

@@ -25,15 +25,20 @@ struct HeadPtrs {
     const float* w[3][8];     // [head][layer] weight
     const float* b[3][8];     // [head][layer] bias
 };
+constexpr int WG_MAX_L = 8;   // generators per batched launch (ghf_weightgen_fwd_batched): kernel arguments stay below 4 KB
+struct HeadPtrsL { HeadPtrs p[WG_MAX_L]; };
 
 // grid (R, 3); block 256.  hidden_ws[(head*R + r)*Hl + j], Hl = num_hidden ? Hh : T.
 // acts (optional): every hidden layer's output, acts[((head*num_hidden + layer)*R + r)*Hh + j]  (the backward's input)
-__global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict__ text_emb, HeadPtrs P,
+// blockIdx.z = generator (layer of the model) of a batched launch: its pointers P.p[z], its slice of hidden_ws
+__global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict__ text_emb, HeadPtrsL PL,
                                                         int R, int T, int Hh, int num_hidden,
                                                         float* __restrict__ hidden_ws, float* __restrict__ acts,
                                                         const float* __restrict__ drop /* acts' layout, or NULL */) {
     __shared__ float buf[2][WG_MAX_WIDTH];
     const int r = blockIdx.x, head = blockIdx.y;
+    const HeadPtrs& P = PL.p[blockIdx.z];
+    if (hidden_ws) hidden_ws += (size_t)blockIdx.z * 3 * R * (num_hidden ? Hh : T);
     for (int k = threadIdx.x; k < T; k += blockDim.x) buf[0][k] = text_emb[(size_t)r * T + k];
     __syncthreads();
     int cur = 0, in_dim = T;
@@ -205,8 +210,10 @@ struct OutHeads {
     int n_out[3];
     size_t rstride[3];
 };
-__global__ __launch_bounds__(256) void wg_out_mfma3_kernel(OutHeads H, int R, int Hl) {
-    const int head = blockIdx.y;
+struct OutHeadsL { OutHeads h[WG_MAX_L]; };
+__global__ __launch_bounds__(256) void wg_out_mfma3_kernel(OutHeadsL HL, int R, int Hl) {
+    const int head = blockIdx.y % 3;
+    const OutHeads& H = HL.h[blockIdx.y / 3];
     const float* __restrict__ z = H.z[head];
     const float* __restrict__ W3 = H.W3[head];
     const float* __restrict__ b3 = H.b3[head];
@@ -248,8 +255,10 @@ __global__ __launch_bounds__(256) void wg_out_mfma3_kernel(OutHeads H, int R, in
 // relation pulls its matrix into LDS, finds the largest magnitude, and rewrites the same bytes as fp16 B fragments
 //   Wh[r][o/16][kk/32][piece][lane = ((kk%32)/8)*16 + o%16][kk%8],  piece 0 = fp16(w 2^s), piece 1 = fp16(w 2^s - piece 0)
 // (4 bytes per weight either way: in place); scales[r] = 2^-s.
-__global__ __launch_bounds__(1024) void wg_pack2h_kernel(float* __restrict__ W, float* __restrict__ scales, int d,
-                                                         int32_t* __restrict__ range_flag) {
+struct PackL { float* W[WG_MAX_L]; };     // per generator of a batched launch: its [R][2d][d] buffer, the scales behind it
+__global__ __launch_bounds__(1024) void wg_pack2h_kernel(PackL WL, int R, int d, int32_t* __restrict__ range_flag) {
+    float* __restrict__ W = WL.W[blockIdx.y];
+    float* __restrict__ scales = W + (size_t)R * 2 * d * d;
     extern __shared__ float wbuf[];                      // [2d][d]
     __shared__ float red[16];
     __shared__ int cnt[2];
@@ -319,14 +328,15 @@ int launch_weightgen_acts(const float* text_emb, const float* const* head_params
     GHF_REQUIRE(R > 0 && T > 0 && num_hidden >= 0 && num_hidden <= 7, "weightgen_acts: bad shape");
     GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen_acts: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
     if (num_hidden == 0) return GHF_OK;
-    HeadPtrs P;
+    HeadPtrsL PL;
+    HeadPtrs& P = PL.p[0];
     const int nl = num_hidden + 1;
     for (int h = 0; h < 3; ++h)
         for (int l = 0; l < nl; ++l) {
             P.w[h][l] = head_params[(h * nl + l) * 2 + 0];
             P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
         }
-    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, nullptr, acts, hidden_drop);
+    wg_hidden_kernel<<<dim3(R, 3, 1), 256, 0, stream>>>(text_emb, PL, R, T, Hh, num_hidden, nullptr, acts, hidden_drop);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
@@ -377,104 +387,125 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
     GHF_LAUNCH_CHECK();
     const size_t lds = (size_t)2 * d * d * 4;
     GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
-    wg_pack2h_kernel<<<R, 1024, lds, stream>>>(out, out + (size_t)R * 2 * d * d, d, range_flag_ptr());
+    PackL WL;
+    WL.W[0] = out;
+    wg_pack2h_kernel<<<dim3(R, 1), 1024, lds, stream>>>(WL, R, d, range_flag_ptr());
     GHF_LAUNCH_CHECK();
+    return GHF_OK;
+}
+
+// L generators of identical shape (the layers of one model) in one launch sequence: hidden layers (grid z = generator), the
+// three heads' output layers (grid y = 3 generators), the SPLIT2H packing (grid y = generator).  head_params / log_scales:
+// generator g's entries at [g * 3 * (num_hidden + 1) * 2 ...] / [g * 3 ...]; hidden_ws: L times the single-call size.
+// Shapes or layouts the merged kernels do not cover run the per-head kernels generator by generator (same results).
+int launch_weightgen_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,
+                             int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
+                             float* hidden_ws, float* const* W_msg, float* const* W_self, float* const* bias,
+                             const float* hidden_drop, hipStream_t stream) {
+    GHF_REQUIRE(L >= 1 && L <= WG_MAX_L, "weightgen: %d generators per call (1..%d)", L, WG_MAX_L);
+    GHF_REQUIRE(R > 0 && T > 0 && d_in > 0 && d_out > 0, "weightgen: R, T, d_in, d_out must be positive");
+    GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
+    GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
+    GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
+    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT2H, "weightgen: bad layout %d", layout);
+    GHF_REQUIRE(!hidden_drop || L == 1, "weightgen: dropout masks go with one generator per call");
+    for (int g = 0; g < L; ++g) {
+        GHF_REQUIRE(W_msg[g] && bias[g], "weightgen: null output pointer (generator %d)", g);
+        if (layout == GHF_WLAYOUT_SPLIT2H)
+            GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && (size_t)2 * d_in * d_out * 4 <= 128 * 1024 && (!W_self || W_self[g] == nullptr),
+                        "weightgen: SPLIT2H needs d_in == d_out, d %% 32 == 0, d <= 128 and W_self == NULL");
+        if (layout == GHF_WLAYOUT_FRAG16)
+            GHF_REQUIRE(d_in == d_out && (d_in % 16) == 0 && (!W_self || W_self[g] == nullptr),
+                        "weightgen: FRAG16 needs d_in == d_out, d %% 16 == 0 and W_self == NULL");
+        else if (layout == GHF_WLAYOUT_NATURAL)
+            GHF_REQUIRE(W_self && W_self[g] != nullptr, "weightgen: NATURAL layout needs W_self");
+    }
+    HeadPtrsL PL;
+    const int nl = num_hidden + 1;
+    for (int g = 0; g < L; ++g)
+        for (int h = 0; h < 3; ++h)
+            for (int l = 0; l < nl; ++l) {
+                PL.p[g].w[h][l] = head_params[((size_t)(g * 3 + h) * nl + l) * 2 + 0];
+                PL.p[g].b[h][l] = head_params[((size_t)(g * 3 + h) * nl + l) * 2 + 1];
+                GHF_REQUIRE(PL.p[g].w[h][l] && PL.p[g].b[h][l], "weightgen: null parameter pointer (generator %d head %d layer %d)", g, h, l);
+            }
+    wg_hidden_kernel<<<dim3(R, 3, L), 256, 0, stream>>>(text_emb, PL, R, T, Hh, num_hidden, hidden_ws, nullptr, hidden_drop);
+    GHF_LAUNCH_CHECK();
+
+    const int Hl = num_hidden ? Hh : T;
+    const int n_mat = d_in * d_out;
+    // natural-order outputs (NATURAL, and SPLIT2H before its packing step): all heads of all generators in one launch when the
+    // MFMA tile applies to each of them
+    bool merged = (layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_SPLIT2H) && (Hl % 16) == 0;
+    OutHeadsL HL;
+    if (merged)
+        for (int g = 0; g < L; ++g) {
+            OutHeads& H = HL.h[g];
+            for (int head = 0; head < 3; ++head) {
+                H.z[head] = hidden_ws + ((size_t)g * 3 + head) * R * Hl;
+                H.W3[head] = PL.p[g].w[head][num_hidden];
+                H.b3[head] = PL.p[g].b[head][num_hidden];
+                H.log_scale[head] = log_scales[g * 3 + head];
+                GHF_REQUIRE(H.log_scale[head], "weightgen: null log-scale pointer (generator %d head %d)", g, head);
+                H.n_out[head] = head == 2 ? d_out : n_mat;
+                H.rstride[head] = (layout == GHF_WLAYOUT_SPLIT2H && head != 2) ? (size_t)2 * n_mat : (size_t)H.n_out[head];
+                H.out[head] = head == 2 ? bias[g] : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg[g] + (size_t)head * n_mat : (head == 0 ? W_msg[g] : W_self[g]));
+                merged = merged && ((((uintptr_t)H.W3[head] | (uintptr_t)H.z[head]) & 15) == 0);
+            }
+        }
+    if (merged) {
+        const int mtiles = (n_mat + 15) / 16;
+        wg_out_mfma3_kernel<<<dim3((mtiles + 3) / 4, 3 * L), 256, 0, stream>>>(HL, R, Hl);
+        GHF_LAUNCH_CHECK();
+    } else {
+        for (int g = 0; g < L; ++g)
+            for (int head = 0; head < 3; ++head) {
+                const float* z = hidden_ws + ((size_t)g * 3 + head) * R * Hl;
+                const float* W3 = PL.p[g].w[head][num_hidden];
+                const float* b3 = PL.p[g].b[head][num_hidden];
+                const float* ls = log_scales[g * 3 + head];
+                GHF_REQUIRE(ls, "weightgen: null log-scale pointer (generator %d head %d)", g, head);
+                const int n_out = head == 2 ? d_out : n_mat;
+                // SPLIT2H: the two matrix heads first write [R][2d][d] fp32 into W_msg (natural order, W_self below W_msg),
+                // which wg_pack2h_kernel then rewrites in place
+                const bool nat = layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_SPLIT2H;
+                const size_t rstride = (layout == GHF_WLAYOUT_SPLIT2H && head != 2) ? (size_t)2 * n_mat : (size_t)n_out;
+                float* out = head == 2 ? bias[g] : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg[g] + (size_t)head * n_mat
+                                                    : (layout != GHF_WLAYOUT_NATURAL ? W_msg[g] : (head == 0 ? W_msg[g] : W_self[g])));
+                const int klayout = nat ? GHF_WLAYOUT_NATURAL : layout;
+                // (the bias head runs the same MFMA chain in every layout: its values do not depend on the layout asked for)
+                const bool mfma_ok = (Hl % 16) == 0 && ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
+                if (mfma_ok && layout == GHF_WLAYOUT_FRAG16 && head != 2) {
+                    const int mtiles = n_mat / 16;
+                    wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(z, W3, b3, ls, R, Hl, n_out, head, d_out, rstride, out);
+                } else if (mfma_ok) {
+                    const int mtiles = (n_out + 15) / 16;
+                    wg_out_mfma_kernel<GHF_WLAYOUT_NATURAL><<<(mtiles + 3) / 4, 256, 0, stream>>>(z, W3, b3, ls, R, Hl, n_out, head, d_out, rstride, out);
+                } else {
+                    wg_out_simple_kernel<<<(n_out + 3) / 4, 256, 0, stream>>>(z, W3, b3, ls, R, Hl, n_out, head, d_in, d_out, klayout, rstride, out);
+                }
+                GHF_LAUNCH_CHECK();
+            }
+    }
+    if (layout == GHF_WLAYOUT_SPLIT2H) {
+        const size_t lds = (size_t)2 * n_mat * 4;
+        PackL WL;
+        for (int g = 0; g < L; ++g) WL.W[g] = W_msg[g];
+        GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
+        wg_pack2h_kernel<<<dim3(R, L), 1024, lds, stream>>>(WL, R, d_out, range_flag_ptr());
+        GHF_LAUNCH_CHECK();
+    }
     return GHF_OK;
 }
 
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                      float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream) {
-    GHF_REQUIRE(R > 0 && T > 0 && d_in > 0 && d_out > 0, "weightgen: R, T, d_in, d_out must be positive");
-    GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
-    GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
-    GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
-    GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT2H, "weightgen: bad layout %d", layout);
-    if (layout == GHF_WLAYOUT_SPLIT2H)
-        GHF_REQUIRE(d_in == d_out && (d_in % 32) == 0 && (size_t)2 * d_in * d_out * 4 <= 128 * 1024 && W_self == nullptr,
-                    "weightgen: SPLIT2H needs d_in == d_out, d %% 32 == 0, d <= 128 and W_self == NULL");
-    if (layout == GHF_WLAYOUT_FRAG16)
-        GHF_REQUIRE(d_in == d_out && (d_in % 16) == 0 && W_self == nullptr,
-                    "weightgen: FRAG16 needs d_in == d_out, d %% 16 == 0 and W_self == NULL");
-    else if (layout == GHF_WLAYOUT_NATURAL)
-        GHF_REQUIRE(W_self != nullptr, "weightgen: NATURAL layout needs W_self");
-
-    HeadPtrs P;
-    const int nl = num_hidden + 1;
-    for (int h = 0; h < 3; ++h)
-        for (int l = 0; l < nl; ++l) {
-            P.w[h][l] = head_params[(h * nl + l) * 2 + 0];
-            P.b[h][l] = head_params[(h * nl + l) * 2 + 1];
-            GHF_REQUIRE(P.w[h][l] && P.b[h][l], "weightgen: null parameter pointer (head %d layer %d)", h, l);
-        }
-    wg_hidden_kernel<<<dim3(R, 3), 256, 0, stream>>>(text_emb, P, R, T, Hh, num_hidden, hidden_ws, nullptr, hidden_drop);
-    GHF_LAUNCH_CHECK();
-
-    const int Hl = num_hidden ? Hh : T;
-    const int n_mat = d_in * d_out;
-    // natural-order outputs (NATURAL, and SPLIT2H before its packing step): all three heads in one launch when the MFMA tile
-    // applies to each of them
-    if (layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_SPLIT2H) {
-        OutHeads H;
-        bool ok = (Hl % 16) == 0;
-        for (int head = 0; head < 3; ++head) {
-            H.z[head] = hidden_ws + (size_t)head * R * Hl;
-            H.W3[head] = P.w[head][num_hidden];
-            H.b3[head] = P.b[head][num_hidden];
-            H.log_scale[head] = log_scales[head];
-            H.n_out[head] = head == 2 ? d_out : n_mat;
-            H.rstride[head] = (layout == GHF_WLAYOUT_SPLIT2H && head != 2) ? (size_t)2 * n_mat : (size_t)H.n_out[head];
-            H.out[head] = head == 2 ? bias : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg + (size_t)head * n_mat : (head == 0 ? W_msg : W_self));
-            ok = ok && ((((uintptr_t)H.W3[head] | (uintptr_t)H.z[head]) & 15) == 0);
-        }
-        if (ok) {
-            const int mtiles = (n_mat + 15) / 16;
-            wg_out_mfma3_kernel<<<dim3((mtiles + 3) / 4, 3), 256, 0, stream>>>(H, R, Hl);
-            GHF_LAUNCH_CHECK();
-            if (layout == GHF_WLAYOUT_SPLIT2H) {
-                const size_t lds = (size_t)2 * n_mat * 4;
-                GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
-                wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out, range_flag_ptr());
-                GHF_LAUNCH_CHECK();
-            }
-            return GHF_OK;
-        }
-    }
-    for (int head = 0; head < 3; ++head) {
-        const float* z = hidden_ws + (size_t)head * R * Hl;
-        const float* W3 = P.w[head][num_hidden];
-        const float* b3 = P.b[head][num_hidden];
-        const int n_out = head == 2 ? d_out : n_mat;
-        // SPLIT2H: the two matrix heads first write [R][2d][d] fp32 into W_msg (natural order, W_self below W_msg),
-        // which wg_pack2h_kernel then rewrites in place
-        const bool nat = layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_SPLIT2H;
-        const size_t rstride = (layout == GHF_WLAYOUT_SPLIT2H && head != 2) ? (size_t)2 * n_mat : (size_t)n_out;
-        float* out = head == 2 ? bias : (layout == GHF_WLAYOUT_SPLIT2H ? W_msg + (size_t)head * n_mat
-                                         : (layout != GHF_WLAYOUT_NATURAL ? W_msg : (head == 0 ? W_msg : W_self)));
-        const int klayout = nat ? GHF_WLAYOUT_NATURAL : layout;
-        // (the bias head runs the same MFMA chain in every layout: its values do not depend on the layout asked for)
-        const bool mfma_ok = (Hl % 16) == 0 && ((((uintptr_t)W3 | (uintptr_t)z) & 15) == 0);
-        if (mfma_ok && layout == GHF_WLAYOUT_FRAG16 && head != 2) {
-            const int mtiles = n_mat / 16;
-            wg_out_mfma_kernel<GHF_WLAYOUT_FRAG16><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
-        } else if (mfma_ok) {
-            const int mtiles = (n_out + 15) / 16;
-            wg_out_mfma_kernel<GHF_WLAYOUT_NATURAL><<<(mtiles + 3) / 4, 256, 0, stream>>>(
-                z, W3, b3, log_scales[head], R, Hl, n_out, head, d_out, rstride, out);
-        } else {
-            wg_out_simple_kernel<<<(n_out + 3) / 4, 256, 0, stream>>>(z, W3, b3, log_scales[head], R, Hl, n_out,
-                                                                      head, d_in, d_out, klayout, rstride, out);
-        }
-        GHF_LAUNCH_CHECK();
-    }
-    if (layout == GHF_WLAYOUT_SPLIT2H) {
-        const size_t lds = (size_t)2 * n_mat * 4;
-        GHF_SET_MAX_LDS(wg_pack2h_kernel, lds);
-        wg_pack2h_kernel<<<R, 1024, lds, stream>>>(W_msg, W_msg + (size_t)R * 2 * n_mat, d_out, range_flag_ptr());
-        GHF_LAUNCH_CHECK();
-    }
-    return GHF_OK;
+    float* wm[1] = {W_msg};
+    float* wsf[1] = {W_self};
+    float* bs[1] = {bias};
+    return launch_weightgen_batched(1, text_emb, head_params, log_scales, R, T, Hh, num_hidden, d_in, d_out, layout, hidden_ws,
+                                    wm, wsf, bs, hidden_drop, stream);
 }
 
 }  // namespace ghf

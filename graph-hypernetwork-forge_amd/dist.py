@@ -155,6 +155,8 @@ class NativeOps:
 
     def all_weights(self, model, text_embs, plan, after=None):
         """([weights of layer l], [event l] or None): every layer's generation on a side stream (HyperGNN.generate_all)."""
+        if model.num_layers <= 8 and os.environ.get("GHF_GEN_BATCHED", "1") != "0":
+            return model.generate_batched(text_embs, plan.wlayout), None      # one launch sequence for all layers, on this stream
         return model.generate_all(text_embs, plan.wlayout, side_stream=plan.E >= model.SIDE_STREAM_MIN_EDGES // 8, after=after)
 
     def split_rows(self, plan, h):

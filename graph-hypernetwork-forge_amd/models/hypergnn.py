@@ -305,6 +305,16 @@ class HyperGNN(nn.Module):
                 return self._forward_recorded(node_features, exact_plan(plan, self.hidden_dim), edge_index, exact=True)
         return h
 
+    def generate_batched(self, text_embs: torch.Tensor, layout: int):
+        """Every layer's (W_msg | Wfrag, W_self | None, bias) from ONE launch sequence (ghf_weightgen_fwd_batched: the layers'
+        generators have identical shapes) — three kernels for all layers on the caller's stream: ~0.11 ms whatever the
+        number of layers, where layer-by-layer generation cost that per layer (between the message launches of a small
+        graph: BASELINE config 2) or needed side streams and events to hide (config 3)."""
+        g0 = self.weight_generators[0]
+        return _native.weightgen_fwd_batched(text_embs, [g._head_params() for g in self.weight_generators],
+                                             [g._log_scale_vector() for g in self.weight_generators], g0.text_dim, g0.hidden_dim,
+                                             g0.num_hidden, g0.d_in, g0.d_out, layout)
+
     def generate_all(self, text_embs: torch.Tensor, layout: int, side_stream: bool = True, after=None, first=None):
         """([weights of layer l], [event l or None]): every layer's weight generation.  The generated weights depend on
         the relation strings only, so on large graphs their ~0.13 ms of small latency-bound kernels per layer are
@@ -400,12 +410,16 @@ class HyperGNN(nn.Module):
         # kernels took 0.4 + 0.3 ms and the first message launch waited for them (kernel-trace timeline, round 3: 0.76 ms
         # before the first message launch).  The later layers' generators run beside the projection on side streams as before.
         side = plan.E >= self.SIDE_STREAM_MIN_EDGES
-        w0 = self.weight_generators[0].generate(text_embs, plan.wlayout) if side and os.environ.get("GHF_GEN0_FIRST", "1") != "0" else None
+        batched = self.num_layers <= 8 and os.environ.get("GHF_GEN_BATCHED", "1") != "0"
+        if batched:                                # all layers' generators in one launch sequence, first (round 3)
+            weights, ready = self.generate_batched(text_embs, plan.wlayout), [None] * self.num_layers
+        w0 = self.weight_generators[0].generate(text_embs, plan.wlayout) if not batched and side and os.environ.get("GHF_GEN0_FIRST", "1") != "0" else None
         h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach(), h_split=hs,
                                    split_layout=plan.wlayout if split else 0)
         h_next = torch.empty_like(h)
         # (enqueued after the input projection: streams can share a hardware queue, and packets queue in host order)
-        weights, ready = self.generate_all(text_embs, plan.wlayout, side_stream=side, after=te_done, first=w0)
+        if not batched:
+            weights, ready = self.generate_all(text_embs, plan.wlayout, side_stream=side, after=te_done, first=w0)
         lo, hi = plan.row_lo, (plan.row_hi or plan.N)
         last = len(self.weight_generators) - 1
         for l, norm in enumerate(self.layer_norms):
@@ -445,8 +459,9 @@ class HyperGNN(nn.Module):
         h_next = torch.empty_like(h)
         Y = rs.scratch(plan.E, self.hidden_dim, device)
         last = len(self.layer_norms) - 1
+        all_w = self.generate_batched(text_embs, _native.WLAYOUT_NATURAL) if self.num_layers <= 8 else None
         for l, (gen, norm) in enumerate(zip(self.weight_generators, self.layer_norms)):
-            W_msg, W_self, bias = gen.generate(text_embs, _native.WLAYOUT_NATURAL)
+            W_msg, W_self, bias = all_w[l] if all_w is not None else gen.generate(text_embs, _native.WLAYOUT_NATURAL)
             if plan.E > 0:
                 _native.edge_transform_fwd(h, rs, W_msg, W_self, bias, Y, h_split=hs)
             _native.segment_tail_fwd(Y, rs, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 11
+#define GHF_ABI_VERSION 12
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -117,6 +117,16 @@ int ghf_weightgen_fwd(const float* text_emb /* [R,T] */, const float* const* hea
                       const float* const* log_scales /* [3] host array of device pointers */, int R, int T, int Hh, int num_hidden,
                       int d_in, int d_out, int layout, float* hidden_ws,
                       float* W_msg, float* W_self, float* bias, const float* hidden_drop /* or NULL */, void* stream);
+
+/* The L generators of one model (identical shapes: the reference builds one WeightGenerator per layer, hypergnn.py:131-143) in
+ * ONE launch sequence — hidden layers, output layers, packing: three kernels for all layers instead of three per layer; on
+ * small graphs the generators' launches are a large share of a forward (BASELINE configs 1 and 2).  head_params: generator
+ * g's pointers at [g * 3 * (num_hidden + 1) * 2 ...] in ghf_weightgen_fwd's order; log_scales [L * 3]; hidden_ws: L times
+ * ghf_weightgen_fwd's size; W_msg / W_self / bias: host arrays of L device pointers (W_self NULL or its entries NULL where
+ * the layout has none).  Inference only (no dropout masks).  L <= 8.  Same values as L calls of ghf_weightgen_fwd. */
+int ghf_weightgen_fwd_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,
+                              int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout, float* hidden_ws,
+                              float* const* W_msg, float* const* W_self, float* const* bias, void* stream);
 
 /* ---- text encoder ------------------------------------------------------------------
  * Replaces models/hypergnn.py:39-81 (TextEncoder) for U strings at once:
