@@ -187,10 +187,10 @@ def test_plan_cache_keys():
     big = ["x"] * (plan_mod.FULL_FINGERPRINT_MAX + 5)
     k3 = PlanCache.key(ei, big, 3, 16, dev)
     assert k3 == PlanCache.key(ei, big, 3, 16, dev)
-    big[plan_mod._SAMPLE_IDX[len(big)][7]] = "y"
+    big[plan_mod._SAMPLE_IDX[len(big)][0][7]] = "y"
     assert k3 != PlanCache.key(ei, big, 3, 16, dev)
     big[-1] = "z"
-    assert len(plan_mod._SAMPLE_IDX[len(big)]) <= plan_mod.SAMPLED_POSITIONS + 2
+    assert len(plan_mod._SAMPLE_IDX[len(big)][0]) <= plan_mod.SAMPLED_POSITIONS + 2
     cache = PlanCache(capacity=2)
     for i in range(3):
         cache.put(("k", i), object(), ei, texts)
