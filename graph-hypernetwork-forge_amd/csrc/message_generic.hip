@@ -127,44 +127,146 @@ __global__ __launch_bounds__(GEN_TPB) void tail_kernel(const float* __restrict__
     tail_store<GEN_TPB / 64>(x, d, red, g, b, eps, h_out + (size_t)v * d);
 }
 
-// Second stage for split destination blocks (hubs): sum the block's partial slots in a fixed order (reproducible), then
-// the K3 tail.  One workgroup per COMB_ROWS destination rows of a split block — a hub block's hundred-odd
-// slots are then read by dozens of workgroups with four loads in flight per lane instead of by one workgroup's serial
-// chain (power-law C3: 4.7 ms -> 0.1 ms).  The grid covers the split blocks only: (items beyond one per block) x (row
-// groups of a block), each workgroup finding its block by a 64-way search (a grid over all blocks cost 77 us per launch at
-// BASELINE config 3, where only the last round's 45 blocks are split).  One wave per destination row, lanes stride
-// the columns.
+// Second stage for split destination blocks (hubs, and the blocks of a launch's last, partly filled round): sum the block's
+// partial slots in a fixed order (reproducible), then the K3 tail.  Grid: (the row range's work items) x COMB_Y; an item of
+// an unsplit block returns at once, item j of a block cut into k items takes the block's groups of rows j, j + k, ... (with
+// blockIdx.y: j + k y, ...) — no search for the block, its id is in the item.  Two kernels: d % 4 == 0 up to 256 on
+// 16-byte accesses, d / 4 lanes per row, every slot's load of a row in flight at once (round 3: the previous kernel — one
+// wave per row, two columns per lane, four loads in flight — took 55-85 us per launch at BASELINE config 3 for 45 blocks of
+// eight slots, 0.25 ms per forward); any d on the old scheme.
 constexpr int COMB_MAX_PER_LANE = GEN_MAX_D / 64;
-constexpr int COMB_ROWS = 8;
-__global__ __launch_bounds__(256) void combine_split_kernel(
-    const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off,
+constexpr int COMB_ROWS = 8, COMB_Y = 6;
+typedef float comb_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 comb_f16x4 __attribute__((ext_vector_type(4)));
+
+struct CombBlock { int64_t blk; int nslots, slot0, j; bool live; };
+__device__ __forceinline__ CombBlock comb_block(const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off, int64_t item0) {
+    const int64_t it = item0 + blockIdx.x;
+    const int64_t blk = item_tab[4 * (size_t)it];
+    const int slot = item_tab[4 * (size_t)it + 3];
+    CombBlock c{blk, 0, 0, 0, slot >= 0};
+    if (!c.live) return c;
+    const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
+    c.nslots = i1 - i0;
+    c.j = (int)(it - i0);
+    c.slot0 = item_tab[4 * (size_t)i0 + 3];
+    return c;
+}
+
+template <int LPR>   // lanes per row: d = 4 LPR
+__global__ __launch_bounds__(256) void combine_split4_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off, int64_t item0,
     const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
-    const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t blk0, int nblk, int64_t row_end,
+    const float* __restrict__ b, float eps, int64_t N, int BN, int64_t row_end,
+    float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail, int32_t* __restrict__ range_flag,
+    float* __restrict__ agg_out) {
+    constexpr int D = 4 * LPR, RPW = 64 / LPR;              // rows per wave and pass
+    const CombBlock cb = comb_block(item_tab, blk_item_off, item0);
+    if (!cb.live) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sub = lane / LPR, c0 = 4 * (lane % LPR);
+    const int64_t node0 = cb.blk * BN;
+    const int nrows_blk = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
+    const int nwg = (int)gridDim.y * cb.nslots;
+    const size_t sstr = (size_t)BN * D;                     // slot stride
+    auto across = [&](float v, bool take_max) -> float {    // over the LPR lanes of a row
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) {
+            const float o = __shfl_xor(v, off);
+            v = take_max ? fmaxf(v, o) : v + o;
+        }
+        return v;
+    };
+    const comb_f32x4 gm = no_tail ? (comb_f32x4){1.f, 1.f, 1.f, 1.f} : *(const comb_f32x4*)(g + c0);
+    const comb_f32x4 bt = no_tail ? (comb_f32x4){0.f, 0.f, 0.f, 0.f} : *(const comb_f32x4*)(b + c0);
+    for (int vb = ((int)blockIdx.y * cb.nslots + cb.j) * (4 * RPW); vb < nrows_blk; vb += nwg * (4 * RPW)) {
+        const int v = vb + RPW * w + sub;
+        const bool live = v < nrows_blk;
+        const int vc = live ? v : nrows_blk - 1;
+        const int64_t node = node0 + vc;
+        const float* __restrict__ p = partial + ((size_t)cb.slot0 * BN + vc) * D + c0;
+        // every load of the row first: the slots (eight at a time), the in-degree, the residual row
+        const int deg = indeg[node];
+        const bool need_h = !no_tail || (no_tail & GHF_FLAG_ADD_H);
+        const comb_f32x4 hv = need_h ? *(const comb_f32x4*)(h + (size_t)node * D + c0) : (comb_f32x4){0.f, 0.f, 0.f, 0.f};
+        comb_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < cb.nslots; j0 += 8) {
+            comb_f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u < cb.nslots ? j0 + u : cb.nslots - 1;         // (past the end: the last slot again, added as zero)
+                x[u] = *(const comb_f32x4*)(p + (size_t)j * sstr);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < cb.nslots) t += x[u];                             // slots in order: reproducible
+        }
+        const float inv = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg > 1 ? deg : 1);
+        t *= inv;
+        if (agg_out && live) *(comb_f32x4*)(agg_out + (size_t)node * D + c0) = t;
+        comb_f32x4 y;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = no_tail ? t[e] + hv[e] : fmaxf(t[e] + hv[e], 0.f);          // (hv = 0 without ADD_H)
+            s += y[e];
+        }
+        if (!no_tail) {
+            const float mean = across(s, false) * (1.0f / D);
+            float var = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float q = y[e] - mean; var += q * q; }
+            const float rstd = 1.0f / sqrtf(across(var, false) * (1.0f / D) + eps);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+        }
+        if (live) *(comb_f32x4*)(h_out + (size_t)node * D + c0) = y;
+        if (h_split_out) {                                 // SPLIT2H: the row's pieces and scale, and its range-guard count
+            float mx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(y[e]));
+            const int sh = split2h_shift(across(mx, true));
+            const float up = pow2f(sh);
+            comb_f16x4 hi4, lo4;
+            float tiny = 0.f, nz = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 hi, lo;
+                split2h(y[e] * up, hi, lo);
+                hi4[e] = hi;
+                lo4[e] = lo;
+                tiny += (float)range_tiny(y[e] * up);
+                nz += y[e] != 0.f ? 1.f : 0.f;
+            }
+            tiny = across(tiny, false);
+            nz = across(nz, false);
+            if (live) {
+                _Float16* sp = (_Float16*)h_split_out + (size_t)node * 2 * D + c0;
+                *(comb_f16x4*)sp = hi4;
+                *(comb_f16x4*)(sp + D) = lo4;
+                if (lane % LPR == 0) {
+                    *(float*)((char*)h_split_out + (size_t)N * D * 4 + (size_t)node * 4) = pow2f(-sh);
+                    range_raise(range_flag, GHF_RANGE_ROWS, (int)tiny, (int)nz);
+                }
+            }
+        }
+    }
+}
+
+// any d: one wave per destination row, lanes stride the columns
+__global__ __launch_bounds__(256) void combine_split_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ item_tab, const int32_t* __restrict__ blk_item_off, int64_t item0,
+    const float* __restrict__ h, const int32_t* __restrict__ indeg, const float* __restrict__ g,
+    const float* __restrict__ b, float eps, int64_t N, int d, int BN, int64_t row_end,
     float* __restrict__ h_out, void* __restrict__ h_split_out, int split_layout, int no_tail, int32_t* __restrict__ range_flag,
     float* __restrict__ agg_out) {
-    // blockIdx.x numbers the range's items beyond one per block: a block of k items owns k - 1 of them, found by bisection
-    // on f(b) = (items before block b) - b; its row groups go round these k - 1 workgroup columns
-    // (64 probes per step, one per lane: two or three dependent loads instead of a bisection's twelve)
-    const int base = blk_item_off[blk0];
-    int lo = 0;
-    for (int span = nblk; span > 1;) {                    // the block is in [lo, lo + span)
-        const int step = (span + 63) >> 6, probe = (int)(threadIdx.x & 63) * step;
-        const bool le = probe < span && blk_item_off[blk0 + lo + probe] - base - (lo + probe) <= (int)blockIdx.x;
-        const int l1 = 63 - __builtin_clzll(__ballot(le));             // f is monotone and f(lo) <= blockIdx.x: the set lanes are a prefix
-        lo += l1 * step;
-        span = span - l1 * step < step ? span - l1 * step : step;
-    }
-    const int64_t blk = blk0 + lo;
-    const int i0 = blk_item_off[blk], i1 = blk_item_off[blk + 1];
-    if (i1 - i0 <= 1) return;
-    const int slot0 = item_tab[4 * (size_t)i0 + 3], nslots = i1 - i0;
+    const CombBlock cb = comb_block(item_tab, blk_item_off, item0);
+    if (!cb.live) return;
+    const int slot0 = cb.slot0, nslots = cb.nslots;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t node0 = blk * BN;
+    const int64_t node0 = cb.blk * BN;
     const int nrows_blk = (int)((row_end - node0) < BN ? (row_end - node0) : BN);
-    // the block's groups of COMB_ROWS rows go round its (nslots - 1) x gridDim.y workgroups (a grid with one workgroup per
-    // group and column — 48 x 7 per block of eight items, six of seven returning at once — took 55 us per launch at BASELINE
-    // config 3: 15 k workgroups, each a chain of dependent loads; now 2.5 k)
-    const int wg = (int)blockIdx.y * (nslots - 1) + ((int)blockIdx.x - (i0 - base - lo)), nwg = (int)gridDim.y * (nslots - 1);
+    const int wg = (int)blockIdx.y * nslots + cb.j, nwg = (int)gridDim.y * nslots;
     for (int vb = wg * COMB_ROWS; vb < nrows_blk; vb += nwg * COMB_ROWS) {
     const int nrows = nrows_blk < vb + COMB_ROWS ? nrows_blk : vb + COMB_ROWS;
     for (int v = vb + w; v < nrows; v += 4) {
@@ -244,17 +346,26 @@ __global__ __launch_bounds__(256) void combine_split_kernel(
 }
 
 int launch_combine_split(const MsgArgs& a, hipStream_t stream) {
-    const int64_t blk0 = a.row0 / a.block_nodes, row_end = a.row0 + a.rows;
-    const int64_t nblk = cdiv(a.rows, a.block_nodes), extra = a.n_items - nblk;     // items beyond one per block
-    if (extra <= 0) return GHF_OK;
-    GHF_REQUIRE(extra < (1ll << 31), "combine_split: too many work items");
-    // gridDim.y x (a block's items - 1) workgroups share a block's row groups: eight rows of them cover a block of eight items
-    // (seven columns) in one pass, a block cut in two (one column) in six
-    static const int ymax = getenv("GHF_COMB_Y") ? atoi(getenv("GHF_COMB_Y")) : 8;
-    const dim3 grid((unsigned)extra, (unsigned)(cdiv(a.block_nodes, COMB_ROWS) < ymax ? cdiv(a.block_nodes, COMB_ROWS) : ymax));
-    combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.h, a.indeg, a.ln_gamma, a.ln_beta,
-                                                   a.ln_eps, a.N, a.d, a.block_nodes, blk0, (int)nblk, row_end, a.h_out, a.h_split_out, a.wlayout,
-                                                   a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);
+    const int64_t row_end = a.row0 + a.rows;
+    const int64_t nblk = cdiv(a.rows, a.block_nodes);
+    if (a.n_items <= nblk) return GHF_OK;                   // no block of the range is split
+    GHF_REQUIRE(a.n_items < (1ll << 31), "combine_split: too many work items");
+    const dim3 grid((unsigned)a.n_items, (unsigned)COMB_Y);
+    const int nt = a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H);
+    const bool vec = (a.d % 4) == 0 && (a.d == 64 || a.d == 128 || a.d == 256) &&
+                     (!a.h_split_out || a.wlayout == GHF_WLAYOUT_SPLIT2H);
+#define GHF_COMB4(LPR)                                                                                                      \
+    combine_split4_kernel<LPR><<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.item0, a.h, a.indeg, a.ln_gamma, \
+                                                        a.ln_beta, a.ln_eps, a.N, a.block_nodes, row_end, a.h_out, a.h_split_out, \
+                                                        nt, range_flag_ptr(), a.agg_out)
+    if (vec && a.d == 64) GHF_COMB4(16);
+    else if (vec && a.d == 128) GHF_COMB4(32);
+    else if (vec && a.d == 256) GHF_COMB4(64);
+    else
+        combine_split_kernel<<<grid, 256, 0, stream>>>(a.partial, a.item_tab, a.blk_item_off, a.item0, a.h, a.indeg, a.ln_gamma, a.ln_beta,
+                                                       a.ln_eps, a.N, a.d, a.block_nodes, row_end, a.h_out, a.h_split_out, a.wlayout,
+                                                       nt, range_flag_ptr(), a.agg_out);
+#undef GHF_COMB4
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
