@@ -102,15 +102,25 @@ def cpu_baseline(cfg, budget_s=12.0, full=None):
     if cfg.get("kind") == "toy":                           # config 1: the reference's demo forward on the same toy graph
         xf, eif, tf = full
         params = synth.hypergnn_params(T, cfg["F"], d, L, seed=7)
-        for _ in range(20):
-            O.forward(params, xf, eif, tf, variant="reference")
-        t0, n = time.time(), 0
-        while time.time() - t0 < min(budget_s, 5.0):
-            O.forward(params, xf, eif, tf, variant="reference")
-            n += 1
-        t = (time.time() - t0) / n
-        return {"value": len(tf) / t, "unit": "edges/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
-                "sample": f"oracle forward (reference op sequence) on the ToyKnowledgeGraph itself, mean of {n} runs",
+        # an 11-edge graph is all fixed cost: with every core of a 128-thread host the intra-op thread pool makes it slower
+        # (37 ms per forward against ~1 ms on one thread) — both are timed, the faster one is the baseline
+        best, all_threads = None, torch.get_num_threads()
+        for threads in sorted({1, all_threads}):
+            torch.set_num_threads(threads)
+            for _ in range(10):
+                O.forward(params, xf, eif, tf, variant="reference")
+            t0, n = time.time(), 0
+            while time.time() - t0 < min(budget_s, 3.0):
+                O.forward(params, xf, eif, tf, variant="reference")
+                n += 1
+            t = (time.time() - t0) / n
+            if best is None or t < best[0]:
+                best = (t, threads, n)
+        torch.set_num_threads(all_threads)
+        t, threads, n = best
+        return {"value": len(tf) / t, "unit": "edges/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+                "sample": f"oracle forward (reference op sequence) on the ToyKnowledgeGraph itself, mean of {n} runs on {threads} "
+                          f"thread(s) (the faster of 1 and {all_threads} threads)",
                 "ms_per_forward": t * 1e3}
     # the reference materialises 4*E*d^2*4 bytes: size the sample to ~8 GB of that
     E = int(min(cfg["E"], max(2000, 8e9 / (16 * d * d))))
@@ -400,8 +410,9 @@ def main():
                         "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e9,
                         "ceiling": L2_STREAM_CEILING_GBS, "unit": "GB/s",
                         "source": "TCC_REQ_sum x 128 B (same PMC file); ceiling measured by tools/micro/l2stream.hip"},
-                    "note": "judged against HBM as BASELINE asks; what binds the kernel is the per-chunk re-streaming of one "
-                            "relation's weights from L2 into each CU plus per-stage fixed latencies (DESIGN.md, Roofline)"}
+                    "note": "judged against HBM as BASELINE asks; the block kernel is bound inside the CU: per (block, relation) chunk "
+                            "the matrix pipe and the vector-memory path (a relation's weights re-streamed from L2) are each busy for "
+                            "~40 % of the chunk's time and the consumer waves' non-matrix work is not overlapped (DESIGN.md §3)"}
         line = {
             "metric": "edges/s (HyperGNN forward)", "value": E / (ms_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
