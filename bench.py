@@ -410,9 +410,10 @@ def main():
                         "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e9,
                         "ceiling": L2_STREAM_CEILING_GBS, "unit": "GB/s",
                         "source": "TCC_REQ_sum x 128 B (same PMC file); ceiling measured by tools/micro/l2stream.hip"},
-                    "note": "judged against HBM as BASELINE asks; the block kernel is bound inside the CU: per (block, relation) chunk "
-                            "the matrix pipe and the vector-memory path (a relation's weights re-streamed from L2) are each busy for "
-                            "~40 % of the chunk's time and the consumer waves' non-matrix work is not overlapped (DESIGN.md §3)"}
+                    "note": "judged against HBM as BASELINE asks; the block kernel is bound inside the CU: the vector-memory return "
+                            "path (TD) is busy ~80 % of the launch — a relation's weights re-streamed from L2 per (block, relation) chunk "
+                            "plus the gathered rows, half of it waiting for L2 / Infinity-Cache data — and the matrix pipe ~34 % "
+                            "(profiles/r03_message_kernel_pipes.json, DESIGN.md §3)"}
         line = {
             "metric": "edges/s (HyperGNN forward)", "value": E / (ms_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
