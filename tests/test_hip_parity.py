@@ -208,6 +208,31 @@ def test_weight_generator_module(golden_dir, c):
         assert_close(got, g[f"{c.name}/{k}"], f"{c.name}/{k}", atol=1e-7)
 
 
+@pytest.mark.parametrize("layout", ["natural", "split2h", "frag16"])
+def test_batched_generators_equal_the_single_calls(layout):
+    """ghf_weightgen_fwd_batched (round 3: all layers' generators in one launch sequence) gives, bit for bit, what one
+    ghf_weightgen_fwd call per layer gives (reference: one WeightGenerator per layer, hypergnn.py:131-143, :278) — in the
+    natural layout (merged output kernel), in SPLIT2H (merged + batched packing) and in FRAG16 (per-head kernels in a loop)."""
+    cfg = cases.MODELS["c3"]
+    model = make_model(cfg)
+    kg = synth.make_kg(50, 400, 23, cfg.node_feat_dim, seed=5)
+    unique, _ = relation_ids(kg.edge_texts())
+    wl = {"natural": _native.WLAYOUT_NATURAL, "split2h": _native.WLAYOUT_SPLIT2H, "frag16": _native.WLAYOUT_FRAG16}[layout]
+    with torch.no_grad():
+        te = model.text_encoder(unique, DEV)
+        batched = model.generate_batched(te, wl)
+        single = [gen.generate(te, wl) for gen in model.weight_generators]
+    torch.cuda.synchronize()
+    assert len(batched) == cfg.num_layers == 3
+    for l in range(cfg.num_layers):
+        for a, b in zip(batched[l], single[l]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), f"layer {l} {layout}"
+    # different layers are different generators: the batched call must not have mixed them up
+    assert not torch.equal(batched[0][2], batched[1][2])
+
+
 def test_frag16_layout_is_a_permutation_of_natural():
     c = [x for x in cases.WG_CASES if x.name == "wg_c3_shape"][0]
     gen = WeightGenerator(c.text_dim, c.d_in, c.d_out, hidden_dim=c.hidden_dim)
