@@ -124,8 +124,32 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.ghf_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libghf_hip.so ABI version {lib.ghf_abi_version()} != {ABI_VERSION}")
+        if os.environ.get("GHF_TRACE_CALLS") == "1":          # diagnostics: name every C-ABI call on stderr and wait for it
+            lib = _Traced(lib)
         _lib = lib
         return lib
+
+
+class _Traced:
+    """GHF_TRACE_CALLS=1: every entry point prints its name before it is enqueued and synchronises the device after — the last
+    name on stderr is the call whose kernel faulted."""
+
+    def __init__(self, lib) -> None:
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("ghf_") or name in ("ghf_last_error", "ghf_abi_version"):
+            return fn
+
+        def call(*args):
+            import sys
+            print(f"[ghf] {name}", file=sys.stderr, flush=True)
+            rc = fn(*args)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return rc
+        return call
 
 
 class GhfError(RuntimeError):

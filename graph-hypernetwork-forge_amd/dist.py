@@ -345,37 +345,42 @@ class ShardedHyperGNN:
         on the device), send[c][q] = the rows of MY slot of chunk c that rank q reads.  One exchange of index lists per
         plan (host tensors through the group: counts by all_gather, lists pairwise)."""
         G, C, me = self.world, spec.chunks, self.rank
+        # the lists travel through the group on the backend's own memory: host tensors over gloo, device tensors over RCCL
+        comm = torch.device("cpu") if self.backend == "gloo" else torch.device(device)
         if plan.E > 0:
             need = torch.unique(self.ops.plan_sources(plan))
             slot = torch.bucketize(need, torch.tensor(spec.bounds[1:], dtype=torch.int64, device=need.device), right=True)
-            need, slot = need.cpu(), slot.cpu()
+            need, slot = need.to(comm), slot.to(comm)
         else:
-            need = slot = torch.zeros(0, dtype=torch.int64)
-        want = [[need[(slot == c * G + p)] if p != me else need[:0] for p in range(G)] for c in range(C)]
-        cnt = torch.tensor([[want[c][p].numel() for p in range(G)] for c in range(C)], dtype=torch.int64)
+            need = slot = torch.zeros(0, dtype=torch.int64, device=comm)
+        want = [[need[(slot == c * G + p)].contiguous() if p != me else need[:0] for p in range(G)] for c in range(C)]
+        cnt = torch.tensor([[want[c][p].numel() for p in range(G)] for c in range(C)], dtype=torch.int64, device=comm)
         allc = [torch.zeros_like(cnt) for _ in range(G)]
         dist.all_gather(allc, cnt, group=self.group)                    # allc[q][c][p]: rows q needs from p in chunk c
-        ops, bufs = [], {}
+        allc = [t.cpu() for t in allc]
+        ops, bufs, keep = [], {}, []
         for p in range(G):
             if p == me:
                 continue
             out = torch.cat([want[c][p] for c in range(C)]) if C else need[:0]
             if out.numel():
+                keep.append(out)
                 ops.append(dist.P2POp(dist.isend, out, p, group=self.group))
             n_in = int(allc[p][:, me].sum())
             if n_in:
-                bufs[p] = torch.empty(n_in, dtype=torch.int64)
+                bufs[p] = torch.empty(n_in, dtype=torch.int64, device=comm)
                 ops.append(dist.P2POp(dist.irecv, bufs[p], p, group=self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        send = [[need[:0].to(device)] * G for _ in range(C)]
+        empty = torch.zeros(0, dtype=torch.int64, device=device)
+        send = [[empty] * G for _ in range(C)]
         for p, t in bufs.items():
             parts = torch.split(t, [int(allc[p][c, me]) for c in range(C)])
             for c in range(C):
-                send[c] = list(send[c])
                 send[c][p] = parts[c].to(device)
         recv = [[want[c][p].to(device) for p in range(G)] for c in range(C)]
+        cnt = cnt.cpu()
         owned = sum(hi - lo for lo, hi in spec.owned())
         return {"send": send, "recv": recv, "rows_needed": int(cnt.sum()), "rows_other": int(spec.N - owned)}
 
