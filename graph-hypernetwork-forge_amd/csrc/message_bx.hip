@@ -139,6 +139,15 @@ __device__ __forceinline__ int opaque_lane(int lane) {
                               // in front of the deferred staging writes; the second phase's in front of the first phase's unscale —
                               // so that their LDS round trip (~370 cycles per stage: tools/stamps_bx.py, "stage prologue") is covered
 #endif
+#ifndef GHF_BX_PLANLATE
+#define GHF_BX_PLANLATE 0     // diagnostics
+#endif
+#ifndef GHF_BX_NOSLEEP
+#define GHF_BX_NOSLEEP 0      // diagnostics
+#endif
+#ifndef GHF_BX_NT
+#define GHF_BX_NT 1           // 1: the source-row gathers are non-temporal loads (each row is read once per block and relation)
+#endif
 #ifndef GHF_BX_PRIO
 #define GHF_BX_PRIO 0
 #endif
@@ -155,10 +164,13 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #define GHF_BX_TGB 3         // tail: four-row groups in flight per wave (six per half at d = 128); measured 1: 3.21, 2: 3.23, 3: 3.18, 4: 3.27 ms
 #endif
 #ifndef GHF_BX64_NPW
-#define GHF_BX64_NPW 64      // hidden 64: nodes per helper wave (one register per node and lane) and rows per chunk
+#define GHF_BX64_NPW 48      // hidden 64: nodes per helper wave (one register per node and lane): blocks of 192 nodes
 #endif
 #ifndef GHF_BX64_CR
-#define GHF_BX64_CR 112
+#define GHF_BX64_CR 64       // hidden 64: rows per chunk (see BxCfg<64>)
+#endif
+#ifndef GHF_BX64_DEFER
+#define GHF_BX64_DEFER 0     // hidden 64: GHF_BX_DEFER's choice for this size (see BxCfg<64>: 1 is NOT reproducible at two workgroups per CU)
 #endif
 
 // Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals per segment.
@@ -187,6 +199,12 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
 #define BX_STAMP_FLUSH()
 #endif
 
+#ifdef GHF_BX_CHECK
+// Diagnostic build (-DGHF_BX_CHECK): consumer wave 0 compares the A tiles in LDS with the rows they should hold (granule slot 0
+// of every live row, both planes) before and after each phase; mismatches go here: [0] = count, then 8 ints per record.
+__device__ int ghf_bx_check_buf[8 + 8 * 8192];
+#endif
+
 template <int D> struct BxCfg;
 template <> struct BxCfg<128> {
     static constexpr int NPW = GHF_BX_NPW, CR = GHF_BX_CR;
@@ -195,9 +213,14 @@ template <> struct BxCfg<128> {
     static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
     static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 512 + 64;
 };
-// hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk decides:
-// long chunks (112 rows = what a 256-node block holds per relation at C2's 32 relations), a small block so that C2's 100 k
-// nodes still make 391 workgroups for 256 CUs
+// hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk (~7,000
+// cycles: barrier, hand-shakes, the descriptor pipeline, two DMA round trips) decides, and two workgroups per CU hide it
+// behind each other: 71 KB of LDS and <= 128 registers per workgroup.  Blocks of 192 nodes: at C2's 32 relations a block and
+// relation hold ~60 rows — one chunk of <= 64 rows, not a full one and a remainder — and C2's 100 k nodes make 521 workgroups
+// for the 512 slots.  Round 3: 0.220 -> 0.155 ms per C2 launch against 256-node blocks, 112-row chunks, one workgroup per CU.
+// GHF_BX64_DEFER = 0 here: with the deferred staging this geometry at two workgroups per CU was NOT bitwise reproducible
+// (a few 8-row fold steps per launch of 170 k went wrong; tools/diag_repro*.py, tools/diag_check.py; the tiles and the ids
+// verified clean in-kernel, GHF_BX_CHECK) — see DESIGN.md, "an unexplained hazard".  Without it: 0 of 300 launches differ.
 template <> struct BxCfg<64> {
     static constexpr int NPW = GHF_BX64_NPW, CR = GHF_BX64_CR;
     static constexpr int BN = 4 * NPW;
@@ -207,17 +230,26 @@ template <> struct BxCfg<64> {
 };
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
-// The helpers' block sums: tuples of 32 registers pinned to v64 .. — every asm that touches them names them with these
-// constraints, so the register allocator keeps them there and the indexed adds can name v64 + index.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// The helpers' block sums: tuples of 32 registers (16 at hidden 64) pinned to v64 .. — every asm that touches them names them
+// with these constraints, so the register allocator keeps them there and the indexed adds can name v64 + index.
 #define BX_PIN_128(s) "+{v[64:95]}"(s[0]), "+{v[96:127]}"(s[1]), "+{v[128:159]}"(s[2]), "+{v[160:191]}"(s[3]), "+{v[192:223]}"(s[4]), "+{v[224:255]}"(s[5])
-#define BX_PIN_64(s) "+{v[64:95]}"(s[0]), "+{v[96:127]}"(s[1])
+#if GHF_BX64_NPW == 64
+#define BX_PIN_64(s) "+{v[64:79]}"(s[0]), "+{v[80:95]}"(s[1]), "+{v[96:111]}"(s[2]), "+{v[112:127]}"(s[3])
+#elif GHF_BX64_NPW == 48
+#define BX_PIN_64(s) "+{v[64:79]}"(s[0]), "+{v[80:95]}"(s[1]), "+{v[96:111]}"(s[2])
+#elif GHF_BX64_NPW == 32
+#define BX_PIN_64(s) "+{v[64:79]}"(s[0]), "+{v[80:95]}"(s[1])
+#else
+#error "GHF_BX64_NPW: 32, 48 or 64"
+#endif
 
 struct BxChunk { int r; int e0; int rows; };
 
 // SKIP: bit 0 = the source half of the weights is zero (GHF_FLAG_ZERO_SRC), bit 1 = the destination half: that half's gathers
 // and products are compiled out (a run-time switch cost the consumers' loop a spilled weight fragment)
 template <int D, int SKIP>
-__global__ __launch_bounds__(512, 2) void message_bx_kernel(
+__global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // (hidden 64: <= 128 registers, two workgroups per CU)
     const float* __restrict__ h, const void* __restrict__ h_split, int64_t N, const uint32_t* __restrict__ sorted_key,
     const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ chunk_tab,
     const int32_t* __restrict__ item_tab, int64_t item0, float* __restrict__ partial,
@@ -229,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     using C = BxCfg<D>;
     constexpr int skip = SKIP;
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, NPW = C::NPW;
+    constexpr bool DEFER = D == 64 ? (GHF_BX64_DEFER != 0) : (GHF_BX_DEFER != 0);
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
     constexpr int KS = D / 32;                // k-steps of 32 per phase
     constexpr int NKS = 2 * KS;
@@ -242,15 +275,16 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     constexpr int CRP = 16 * MTC;             // rows an A tile is read as (the last tile's dead rows are never used)
     constexpr int MSTR = 4 * CRP + 4;         // words per chunk descriptor: sc_u, sc_v, src id, dst id [CRP each], rows
     constexpr int PL = D / 64;                // sum positions (registers) per node and helper lane
-    constexpr int NSV = NPW * PL / 32;        // tuples of 32 registers that hold a helper lane's sums
+    constexpr int TUP = D == 128 ? 32 : 16;   // registers per tuple of sums
+    constexpr int NSV = NPW * PL / TUP;       // tuples that hold a helper lane's sums
     constexpr int RPP = 1024 / ROWB;          // rows per 1 KiB DMA piece of a plane (4 at d = 128, 8 at d = 64)
     constexpr int LPR = 64 / RPP;             // lanes (16-byte granules) per row of a piece
     constexpr int RBN = CR / RPP;             // pieces per plane
     constexpr int CPL = D / 16;               // tail: columns per lane (16 lanes per row)
     constexpr int RBW = (RBN + TW - 1) / TW;  // pieces per helper wave and plane
     constexpr int RPH = (CR + TW - 1) / TW;   // rows of a descriptor per helper wave
-    static_assert((NTW == 2 || NTW == 1) && CR % RPP == 0 && RPH <= 64 && NPW * TW == BN && (NPW * PL) % 64 == 0 && NPW * PL <= 192 &&
-                      CR <= 128 && (NSV == 6 || NSV == 2) && (D == 128 || D == 64), "bad config");
+    static_assert((NTW == 2 || NTW == 1) && CR % RPP == 0 && RPH <= 64 && NPW * TW == BN && (NPW * PL) % TUP == 0 && NPW * PL <= 192 &&
+                      NPW % 2 == 0 && (BN / 2) % 4 == 0 && CR <= 128 && NSV <= 6 && (D == 128 || D == 64), "bad config");
     // the XOR key of a row's 16-byte granules in an A tile: 16 granules per row at d = 128 (key = row mod 16); 8 at d = 64, where
     // two rows share a 256-byte bank line, so the key is (row / 2) mod 8 — either way the 16 rows of a fragment read hit every
     // bank once
@@ -452,11 +486,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
     };
 
     if (helper) {
-        f32x32 sm[NSV];                                                 // the block sums (see header): register PL*n + e = position
+        typename std::conditional<D == 128, f32x32, f32x16>::type sm[NSV];   // the block sums (see header): register PL*n + e = position
 #pragma unroll                                                          // PL*lane + e of this wave's node n
         for (int k = 0; k < NSV; ++k)
 #pragma unroll
-            for (int i = 0; i < 32; ++i) sm[k][i] = 0.f;
+            for (int i = 0; i < TUP; ++i) sm[k][i] = 0.f;
         if constexpr (D == 128) asm volatile("" : BX_PIN_128(sm)); else asm volatile("" : BX_PIN_64(sm));
         // ================================================ HELPERS ================================================
         const int hw = tw;
@@ -524,10 +558,34 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 }
             }
         };
-        auto dma_tile = [&](unsigned tile_off, int j, int which, int rows, bool nt, int lane) {
+#ifdef GHF_BX_CHECK
+        // the ids a DMA is about to use, against the edge arrays (records: code 8 + which)
+        auto check_ids = [&](const BxChunk& c, int which, int kk, int lane, const int (&id)[6]) {
+#pragma unroll
+            for (int i = 0; i < RBW; ++i) {
+                const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
+                if (row < c.rows && (lane & (LPR - 1)) == 0) {
+                    const int want = which == 2 ? (sorted_src[c.e0 + row] & SRC_MASK)
+                                                : (int)((uint32_t)node0 + (sorted_key[c.e0 + row] - (seg0 + (uint32_t)c.r) * (uint32_t)BN));
+                    if (id[i] != want) {
+                        const int slot_i = atomicAdd(&ghf_bx_check_buf[0], 1);
+                        if (slot_i < 8192) {
+                            int* o = ghf_bx_check_buf + 8 + 8 * slot_i;
+                            o[0] = (int)blk; o[1] = kk; o[2] = row; o[3] = (8 + which) * 16 + which * 4; o[4] = id[i]; o[5] = want; o[6] = hw; o[7] = c.rows;
+                        }
+                    }
+                }
+            }
+        };
+#define BX_CHECK_IDS(c, which, kk, lane, id) check_ids(c, which, kk, lane, id)
+#else
+#define BX_CHECK_IDS(c, which, kk, lane, id)
+#endif
+        auto dma_tile = [&](unsigned tile_off, int j, int which, const BxChunk& c, bool nt, int lane) {
             int id[6];
             dma_ids(j, which, lane, id);
-            dma_issue(tile_off, rows, nt, lane, id);
+            BX_CHECK_IDS(c, which, j, lane, id);
+            dma_issue(tile_off, c.rows, nt, lane, id);
         };
         // ---- fold chunk j's staged rows into the registers, row by row -------------------------------------------
         // Y [row][position], the two 32-position halves of a 64-position group swapped when (row >> 2) & 1 (the consumers'
@@ -621,7 +679,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(flags) : "memory");
                 const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (__builtin_amdgcn_readfirstlane(lo) >= v) break;
+#if !GHF_BX_NOSLEEP
                 __builtin_amdgcn_s_sleep(1);
+#endif
             }
         };
 
@@ -665,8 +725,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
         __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0 and 1 visible to all helper waves
         // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
         if (nchunks > 0) {
-            if (!(skip & 1)) dma_tile(P0_OFF, 0, 2, ch[0].rows, true, lane);
-            if (!(skip & 2)) dma_tile(P1_OFF, 0, 3, ch[0].rows, false, lane);
+            if (!(skip & 1)) dma_tile(P0_OFF, 0, 2, ch[0], GHF_BX_NT != 0, lane);
+            if (!(skip & 2)) dma_tile(P1_OFF, 0, 3, ch[0], false, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (GHF_BX_LATE && lane == 0) lds_st_b32(lds0 + FLAG_OFF + 32 + 4 * hw, 1);   // chunk 0's destination rows are in
         }
@@ -689,8 +749,9 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
-            if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, true, l0, sid);
-            if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1].rows, false, l0);
+            if (!(skip & 1) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], 2, k + 1, l0, sid);
+            if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, GHF_BX_NT != 0, l0, sid);
+            if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1], false, l0);
             if (GHF_BX_LATE && N_DST > 0) {
                 // chunk k's destination rows (requested at the end of chunk k-1) have landed once only the source-row DMAs
                 // just issued are in flight: tell the consumers, who need that tile for phase 1 only
@@ -701,8 +762,13 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             }
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
+#if GHF_BX_PLANLATE
+                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);
                 const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
-                if (GHF_BX_DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
+#else
+                const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
+                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
+#endif
                 BX_STAMP(5);                               // (stamps: the wait for the staged rows)
                 fold_rows(k - 1, fp, l0);
             }
@@ -725,6 +791,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 wdL = load_words(ch[4], l1);
             }
             d5 = load_desc(k + 5);
+            if (!YT && !(skip & 2) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], 3, k + 1, l1, did);
             if (!YT && !(skip & 2)) dma_issue(P1_OFF + ((k + 1) & 1) * TILE, ch[1].rows, false, l1, did);
             BX_STAMP(1);
             prev_rows = ch[0].rows;
@@ -758,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
 #pragma unroll
                 for (int e = 0; e < PL; ++e) {
                     const int reg = PL * (H * HPW + i) + e;
-                    o[i * D + 16 * e] = sm[reg / 32][reg % 32];
+                    o[i * D + 16 * e] = sm[reg / TUP][reg % TUP];
                 }
         };
         __syncthreads();
@@ -943,6 +1010,31 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 }
             }
         };
+#ifdef GHF_BX_CHECK
+        auto check_tile = [&](unsigned tile_off, int which, const int* meta, const BxChunk& c, int kk, int code) {
+            if (tw != 0) return;
+            for (int r = lane; r < c.rows; r += 64) {
+                const int id = meta[which * CRP + r];
+                const int want_id = which == 2 ? (sorted_src[c.e0 + r] & SRC_MASK)
+                                               : (int)((uint32_t)node0 + (sorted_key[c.e0 + r] - (seg0 + (uint32_t)c.r) * (uint32_t)BN));
+                for (int pl = 0; pl < NPL; ++pl) {
+                    const i32x4 lv = *(const i32x4*)(smem + tile_off + pl * PLANE + r * ROWB);
+                    const i32x4 gv = *(const i32x4*)((const char*)h_split + (size_t)want_id * HROW + pl * ROWB + (akey(r) << 4));
+                    const bool bad = lv[0] != gv[0] || lv[1] != gv[1] || lv[2] != gv[2] || lv[3] != gv[3] || id != want_id;
+                    if (bad) {
+                        const int slot_i = atomicAdd(&ghf_bx_check_buf[0], 1);
+                        if (slot_i < 8192) {
+                            int* o = ghf_bx_check_buf + 8 + 8 * slot_i;
+                            o[0] = (int)blk; o[1] = kk; o[2] = r; o[3] = code * 16 + which * 4 + pl; o[4] = id; o[5] = want_id; o[6] = lv[0]; o[7] = gv[0];
+                        }
+                    }
+                }
+            }
+        };
+#define BX_CHECK(tile, which, code) check_tile(tile, which, meta, ch, k, code)
+#else
+#define BX_CHECK(tile, which, code)
+#endif
         auto nothing = [](int) {};
         const int ph_first = skip & 1;                     // the first live phase of a chunk
         BxChunk ch{0, 0, 1};
@@ -954,7 +1046,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             for (int t = 0; t < NTW; ++t) bv[t] = *bx_at<float>(bias, (uint32_t)(r * D + (tw * NTW + t) * 16 + c16) * 4u);
         };
         int mt_prev = 0;
-        static_assert(!(GHF_BX_DEFER && GHF_BX_YT), "GHF_BX_DEFER stages into the aliased tile");
+        static_assert(!(DEFER && YT), "GHF_BX_DEFER stages into the aliased tile");
         if (nchunks > 0) {
             ch = decode(load_desc(0));
             dn = load_desc(1);
@@ -976,8 +1068,8 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
             // GHF_BX_DEFER: the previous chunk's rows go to their staging tile (that chunk's destination-row tile) only now:
             // behind the barrier every consumer wave is through with that tile, so there is no hand-shake among the consumers,
             // and the accumulators are not needed before this chunk's first phase ends.  The helpers wait for the flag.
-            constexpr bool ILV = GHF_BX_ILV && GHF_BX_DEFER && !(skip & 1) && !(GHF_BXEXP & 16);
-            if (GHF_BX_DEFER && k > 0 && !ILV) {
+            constexpr bool ILV = GHF_BX_ILV && DEFER && !(skip & 1) && !(GHF_BXEXP & 16);
+            if (DEFER && k > 0 && !ILV) {
                 if (!(GHF_BXEXP & 16)) write_rows(mt_prev, P1_OFF + ((k - 1) & 1) * TILE);
 #if GHF_BX_FLAGWAIT
                 BX_LGKM0();
@@ -986,6 +1078,7 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 BX_STAMP(3);
             }
             const BxChunk nx = decode(dn);
+            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, 2, 0);
             // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
             // behind the first phase's k-steps: this chunk's destination rows have landed (helpers' flags) -> the second phase's
             // first fragments are requested before the first phase's unscale
@@ -1019,9 +1112,11 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                 if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
             }
             BX_STAMP(1);
+            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, 2, 1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
             if (GHF_BX_LATE && !(skip & 2) && !YT && !PRE1) wait_landed();   // the destination-row tile of this chunk has landed (helpers' flags)
+            if (!(skip & 2)) BX_CHECK(P1_OFF + (k & 1) * TILE, 3, 2);
             if (skip & 1) {                                // no source phase ran: the destination phase adds to the bias
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
@@ -1029,16 +1124,17 @@ __global__ __launch_bounds__(512, 2) void message_bx_kernel(
                     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){bias_v[t], bias_v[t], bias_v[t], bias_v[t]};
             }
             if (!(skip & 2)) stage_for(mt, pre1_t{}, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing, no_after);
+            if (!(skip & 2)) BX_CHECK(P1_OFF + (k & 1) * TILE, 3, 3);
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
             // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it
             // the last chunk (and every chunk without GHF_BX_DEFER) stages its rows here, once all four consumer waves have read
             // the tile they overwrite (flag words; YT: once every helper wave has folded the previous chunk's rows)
-            const bool stage_now = !GHF_BX_DEFER || k + 1 == nchunks;
+            const bool stage_now = !DEFER || k + 1 == nchunks;
             if (stage_now) {
-                const unsigned fw = GHF_BX_DEFER ? FLAG_OFF + 48 : FLAG_OFF + (YT ? 0 : 16);      // (DEFER: words of their own)
-                const int fv = GHF_BX_DEFER ? 1 : k + 1;
-                if (!YT && lane == 0) lds_st_b32(lds0 + (GHF_BX_DEFER ? FLAG_OFF + 48 : FLAG_OFF + 16) + 4 * tw, fv);
+                const unsigned fw = DEFER ? FLAG_OFF + 48 : FLAG_OFF + (YT ? 0 : 16);      // (DEFER: words of their own)
+                const int fv = DEFER ? 1 : k + 1;
+                if (!YT && lane == 0) lds_st_b32(lds0 + (DEFER ? FLAG_OFF + 48 : FLAG_OFF + 16) + 4 * tw, fv);
                 for (;;) {
                     i32x4 f;
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + fw) : "memory");
@@ -1094,10 +1190,13 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(bx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(bx): split blocks need the `partial` scratch");
     const int skip = ((a.flags & GHF_FLAG_ZERO_SRC) ? 1 : 0) | ((a.flags & GHF_FLAG_ZERO_DST) ? 2 : 0);
+    // GHF_BX_LDS_PAD=<bytes> (diagnostics): a larger LDS request — e.g. one workgroup per CU where two would fit
+    static const size_t lds_pad = [] { const char* e = getenv("GHF_BX_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t lds_dyn = lds + lds_pad <= 160 * 1024 ? lds + lds_pad : lds;
     auto go = [&](auto skip_c) {
         constexpr int S = decltype(skip_c)::value;
-        GHF_SET_MAX_LDS((message_bx_kernel<D, S>), lds);
-        message_bx_kernel<D, S><<<(unsigned)a.n_items, 512, lds, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
+        GHF_SET_MAX_LDS((message_bx_kernel<D, S>), lds_dyn);
+        message_bx_kernel<D, S><<<(unsigned)a.n_items, 512, lds_dyn, stream>>>(a.h, a.h_split, a.N, a.sorted_key, a.sorted_src, a.chunk_tab, a.item_tab,
                                                                           a.item0, a.partial, a.indeg, a.R, a.W_msg, a.bias, a.ln_gamma,
                                                                           a.ln_beta, a.ln_eps, a.row0, row_end, a.h_out, a.h_split_out,
                                                                           a.flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM | GHF_FLAG_ADD_H), range_flag_ptr(), a.agg_out);
@@ -1168,6 +1267,13 @@ int launch_message_bx(const MsgArgs& a, hipStream_t stream) {
 
 }  // namespace ghf
 
+#ifdef GHF_BX_CHECK
+extern "C" int ghf_debug_read_check_bx(int* host, size_t count, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_check_buf), count * sizeof(int));
+    if (reset) { int z = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(ghf::ghf_bx_check_buf), &z, sizeof(int)); }
+    return rc;
+}
+#endif
 #ifdef GHF_STAMPS
 extern "C" int ghf_debug_read_stamps_bx(unsigned long long* host, size_t count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_stamp_buf), count * sizeof(unsigned long long));

@@ -45,7 +45,7 @@ def test_abi_argument_validation_without_a_gpu():
     assert lib.ghf_split_rows_bytes(10, 128, 3) == 10 * 128 * 4 + 40 and lib.ghf_split_rows_bytes(10, 128, 2) == 0
     assert lib.ghf_split_rows_bytes(10, 128, 1) == 0
     assert lib.ghf_weights_bytes(4, 128, 128, 3) == 4 * 2 * 128 * 128 * 4 + 16 and lib.ghf_weights_bytes(4, 8, 24, 0) == 4 * 8 * 24 * 4
-    assert lib.ghf_message_config(64, ref(bn), ref(wl), ref(cr), ref(sc)) == 0 and (bn.value, wl.value, cr.value) == (256, 3, 112)
+    assert lib.ghf_message_config(64, ref(bn), ref(wl), ref(cr), ref(sc)) == 0 and (bn.value, wl.value, cr.value) == (192, 3, 64)
     assert lib.ghf_message_config(20, ref(bn), ref(wl), ref(cr), ref(sc)) == 0
     assert (bn.value, wl.value, cr.value, sc.value) == (1, 0, 0, 0)
     assert lib.ghf_message_config(16, None, None, None, None) == -1
