@@ -145,7 +145,12 @@ class _SplitCarry:
         self.ref, self.version, self.split = weakref.ref(h), h._version, split
 
 
-_EO_SIDE = os.environ.get("GHF_EO_SIDE", "1") != "0"          # (C3 training step 49.1 -> 48.7 ms)
+# GHF_EO_SIDE=1: the weight gradients on a second stream beside the two gradient passes.  Round 2: 49.1 -> 48.7 ms per C3
+# training step.  Round 3 (same box, tools/ab_train.sh): 45.0-45.9 ms with, 45.1-45.5 without — the three kernels contend for
+# the same gather path (the self-term pass took 4.8 ms beside the contraction, 2.3 alone): off, one stream fewer.
+_EO_SIDE = os.environ.get("GHF_EO_SIDE", "0") != "0"
+_ONE_PACK = os.environ.get("GHF_BWD_ONE_PACK", "1") != "0"   # the two gradient passes share one packed weight tensor (three pack
+                                                             # launches fewer per step; within the box noise of tools/ab_train.sh)
 _SIDE_STREAMS: dict = {}
 
 
@@ -215,8 +220,13 @@ class MessageLayerFn(torch.autograd.Function):
         dh = None
         if ctx.needs_input_grad[0]:
             zero_b = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)
-            Wf, Wf2 = _layer_weights(plan, None, W_self.detach(), transpose=True)       # self term: rows keyed by destination
-            Wr, Wr2 = _layer_weights(tp.rev, W_msg.detach(), None, transpose=True)      # message term: scattered to the sources
+            if _ONE_PACK and plan.wlayout == tp.rev.wlayout and plan.wlayout in _native.SPLIT_LAYOUTS:
+                # one packed tensor serves both passes: each declares the half it does not read zero (ZERO_SRC / ZERO_DST)
+                Wf, Wf2 = _layer_weights(plan, W_msg.detach(), W_self.detach(), transpose=True)
+                Wr, Wr2 = Wf, Wf2
+            else:
+                Wf, Wf2 = _layer_weights(plan, None, W_self.detach(), transpose=True)       # self term: rows keyed by destination
+                Wr, Wr2 = _layer_weights(tp.rev, W_msg.detach(), None, transpose=True)      # message term: scattered to the sources
             if Gs is not None and _native.side_output_supported(plan, h.size(1)) and _native.side_output_supported(tp.rev, h.size(1)):
                 # the three terms are added in the two passes' tails: dpre + self term, then + message term
                 t1 = _raw_message(G, plan, Wf, Wf2, zero_b, _native.GHF_FLAG_ZERO_SRC, Gs, residual=dpre)

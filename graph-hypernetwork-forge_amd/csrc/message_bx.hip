@@ -259,7 +259,14 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
     int64_t row0, int64_t row_end, float* __restrict__ h_out, void* __restrict__ h_split_out, int no_tail,
     int32_t* __restrict__ range_flag, float* __restrict__ agg_out) {
     using C = BxCfg<D>;
-    constexpr int skip = SKIP;
+    // ZERO_SRC (SKIP = 1, the backward's pass over the forward plan) runs as the one-phase kernel of ZERO_DST does — its rows
+    // gathered a whole chunk ahead into the P0 tiles, no hand-shake for a late tile — with the destination ids, the
+    // destination half of the weights and the destination rows' scales in that phase: as a second phase without a first one
+    // its gathers were issued behind the fold and waited for at the next chunk's start (4.85 ms per C3 launch against 2.3)
+    constexpr int skip = SKIP == 1 ? 2 : SKIP;
+    constexpr int P0_IDS = SKIP == 1 ? 3 : 2;      // which ids the P0 tiles' rows follow (2: source, 3: destination)
+    constexpr int P0_HALF = SKIP == 1 ? 1 : 0;     // the half of the weights (and the row scales) of the P0 phase
+    constexpr bool P0_NT = GHF_BX_NT != 0 && SKIP != 1;   // (a destination row is gathered once per in-edge: default cache policy)
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, NPW = C::NPW;
     constexpr bool DEFER = D == 64 ? (GHF_BX64_DEFER != 0) : (GHF_BX_DEFER != 0);
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
@@ -725,7 +732,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0 and 1 visible to all helper waves
         // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
         if (nchunks > 0) {
-            if (!(skip & 1)) dma_tile(P0_OFF, 0, 2, ch[0], GHF_BX_NT != 0, lane);
+            if (!(skip & 1)) dma_tile(P0_OFF, 0, P0_IDS, ch[0], P0_NT, lane);
             if (!(skip & 2)) dma_tile(P1_OFF, 0, 3, ch[0], false, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (GHF_BX_LATE && lane == 0) lds_st_b32(lds0 + FLAG_OFF + 32 + 4 * hw, 1);   // chunk 0's destination rows are in
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         // DMA instructions per tile and helper wave (constant: dma_tile) — what the counted waits below leave in flight
         constexpr int N_SRC = (skip & 1) ? 0 : RBW * NPL, N_DST = ((skip & 2) || YT) ? 0 : RBW * NPL;
         int sid[6] = {0, 0, 0, 0, 0, 0};                   // source ids of the NEXT chunk's rows (read at the end of a chunk)
-        if (nchunks > 0 && !(skip & 1)) dma_ids(1, 2, lane, sid);
+        if (nchunks > 0 && !(skip & 1)) dma_ids(1, P0_IDS, lane, sid);
         for (int k = 0; k < nchunks; ++k) {
             __builtin_amdgcn_s_barrier();                  // ---- chunk k
             BX_STAMP(0);
@@ -749,8 +756,8 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             }
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
-            if (!(skip & 1) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], 2, k + 1, l0, sid);
-            if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, GHF_BX_NT != 0, l0, sid);
+            if (!(skip & 1) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], P0_IDS, k + 1, l0, sid);
+            if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, P0_NT, l0, sid);
             if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1], false, l0);
             if (GHF_BX_LATE && N_DST > 0) {
                 // chunk k's destination rows (requested at the end of chunk k-1) have landed once only the source-row DMAs
@@ -795,7 +802,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             if (!YT && !(skip & 2)) dma_issue(P1_OFF + ((k + 1) & 1) * TILE, ch[1].rows, false, l1, did);
             BX_STAMP(1);
             prev_rows = ch[0].rows;
-            if (!(skip & 1)) dma_ids(k + 2, 2, l1, sid);     // (published at this chunk's start by every helper wave; all are past their flag)
+            if (!(skip & 1)) dma_ids(k + 2, P0_IDS, l1, sid);     // (published at this chunk's start by every helper wave; all are past their flag)
             // the source rows of chunk k+1 (requested at this chunk's start) must be in before the barrier; GHF_BX_LATE: the
             // destination-row DMAs issued last stay in flight across it
             // (counted in DMA instructions only — one per builtin; the descriptor loads before them are waited for as well:
@@ -880,7 +887,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
             for (int p = 0; p < AD; ++p) lda_from(Abuf, 0, p, apre[p]);
         };
-        auto compute_stage = [&](auto mt_c, auto pre_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+        auto compute_stage = [&](auto mt_c, auto pre_c, int ph, bool first, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
                                  const float (&bias_v)[NTW], auto&& between, auto&& after_k) __attribute__((always_inline)) {
             constexpr int MT = decltype(mt_c)::value;
             constexpr bool PRE = decltype(pre_c)::value;
@@ -953,7 +960,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 for (int s = 0; s < 4; ++s) {
                     const float f = sc[m][s] * wscale;
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) acc[m][t][s] = fmaf(part[m][t][s], f, ph == 0 ? bias_v[t] : acc[m][t][s]);
+                    for (int t = 0; t < NTW; ++t) acc[m][t][s] = fmaf(part[m][t][s], f, first ? bias_v[t] : acc[m][t][s]);
                 }
             }
             // (the tiles this instance does not compute: defined here, so that their old values need not survive the stage)
@@ -962,14 +969,14 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         };
-        auto stage_for = [&](int mt, auto pre_c, int ph, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
+        auto stage_for = [&](int mt, auto pre_c, int ph, bool first, const char* Abuf, const int* meta, float wscale, int r_next, int ph_next,
                              const float (&bias_v)[NTW], auto&& between, auto&& after_k) __attribute__((always_inline)) {
             // three instances: all tiles, one fewer, two fewer (shorter chunks — 7 % at C3 — run the last one: their dead
             // tiles cost MFMAs on stale rows that are never written)
             static_assert(MTC >= 3, "three compute_stage instances");
-            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, pre_c, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
-            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, pre_c, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
-            else compute_stage(std::integral_constant<int, MTC - 2>{}, pre_c, ph, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
+            if (mt >= MTC) compute_stage(std::integral_constant<int, MTC>{}, pre_c, ph, first, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
+            else if (mt == MTC - 1) compute_stage(std::integral_constant<int, MTC - 1>{}, pre_c, ph, first, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
+            else compute_stage(std::integral_constant<int, MTC - 2>{}, pre_c, ph, first, Abuf, meta, wscale, r_next, ph_next, bias_v, between, after_k);
         };
         // a chunk's finished rows -> Y: lane (q, c16) holds rows 16m + 4q + s, positions 32tw + 2c16 + t (t = 0, 1) — with one
         // fragment per wave (d = 64), position 16tw + c16
@@ -1036,7 +1043,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #define BX_CHECK(tile, which, code)
 #endif
         auto nothing = [](int) {};
-        const int ph_first = skip & 1;                     // the first live phase of a chunk
+        const int ph_first = (skip & 1) ? 1 : P0_HALF;      // the weights' half of a chunk's first live phase
         BxChunk ch{0, 0, 1};
         i32x2 dn{0, 0};
         float bias_v[NTW] = {}, bias_n[NTW] = {}, wscale = 1.f, wscale_n = 1.f;
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 BX_STAMP(3);
             }
             const BxChunk nx = decode(dn);
-            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, 2, 0);
+            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, P0_IDS, 0);
             // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
             // behind the first phase's k-steps: this chunk's destination rows have landed (helpers' flags) -> the second phase's
             // first fragments are requested before the first phase's unscale
@@ -1101,10 +1108,10 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             if (!(skip & 1)) {
                 if (ILV && k > 0) {
                     const unsigned ytile = P1_OFF + ((k - 1) & 1) * TILE;
-                    stage_for(mt, pre0_t{}, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v,
+                    stage_for(mt, pre0_t{}, P0_HALF, true, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? P0_HALF : 1, bias_v,
                               [&](int j) __attribute__((always_inline)) { write_rows_slice(j, ytile); }, next_pre);
                 } else {
-                    stage_for(mt, pre0_t{}, 0, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? 0 : 1, bias_v, nothing, next_pre);
+                    stage_for(mt, pre0_t{}, P0_HALF, true, smem + P0_OFF + (k & 1) * TILE, meta, wscale, (skip & 2) ? nx.r : ch.r, (skip & 2) ? P0_HALF : 1, bias_v, nothing, next_pre);
                 }
             }
             if (ILV && k > 0) {                            // (the stage's unscale has not touched acc's OLD values before this point:
@@ -1112,7 +1119,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
             }
             BX_STAMP(1);
-            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, 2, 1);
+            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, P0_IDS, 1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
             if (GHF_BX_LATE && !(skip & 2) && !YT && !PRE1) wait_landed();   // the destination-row tile of this chunk has landed (helpers' flags)
@@ -1123,7 +1130,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){bias_v[t], bias_v[t], bias_v[t], bias_v[t]};
             }
-            if (!(skip & 2)) stage_for(mt, pre1_t{}, 1, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing, no_after);
+            if (!(skip & 2)) stage_for(mt, pre1_t{}, 1, false, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing, no_after);
             if (!(skip & 2)) BX_CHECK(P1_OFF + (k & 1) * TILE, 3, 3);
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
