@@ -147,7 +147,7 @@ class _SplitCarry:
 
 # GHF_EO_SIDE=1: the weight gradients on a second stream beside the two gradient passes.  Round 2: 49.1 -> 48.7 ms per C3
 # training step.  Round 3 (same box, tools/ab_train.sh): 45.0-45.9 ms with, 45.1-45.5 without — the three kernels contend for
-# the same gather path (the self-term pass took 4.8 ms beside the contraction, 2.3 alone): off, one stream fewer.
+# the same gather path (beside the contraction the self-term pass took 4.8 ms, alone 2.4): off, one stream fewer.
 _EO_SIDE = os.environ.get("GHF_EO_SIDE", "0") != "0"
 _ONE_PACK = os.environ.get("GHF_BWD_ONE_PACK", "1") != "0"   # the two gradient passes share one packed weight tensor (three pack
                                                              # launches fewer per step; within the box noise of tools/ab_train.sh)

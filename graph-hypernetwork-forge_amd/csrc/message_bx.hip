@@ -139,6 +139,9 @@ __device__ __forceinline__ int opaque_lane(int lane) {
                               // in front of the deferred staging writes; the second phase's in front of the first phase's unscale —
                               // so that their LDS round trip (~370 cycles per stage: tools/stamps_bx.py, "stage prologue") is covered
 #endif
+#ifndef GHF_BX_SWAP1
+#define GHF_BX_SWAP1 1        // 0 (A/B): ZERO_SRC as a second phase without a first one, as in round 2
+#endif
 #ifndef GHF_BX_PLANLATE
 #define GHF_BX_PLANLATE 0     // diagnostics
 #endif
@@ -262,11 +265,14 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
     // ZERO_SRC (SKIP = 1, the backward's pass over the forward plan) runs as the one-phase kernel of ZERO_DST does — its rows
     // gathered a whole chunk ahead into the P0 tiles, no hand-shake for a late tile — with the destination ids, the
     // destination half of the weights and the destination rows' scales in that phase: as a second phase without a first one
-    // its gathers were issued behind the fold and waited for at the next chunk's start (4.85 ms per C3 launch against 2.3)
-    constexpr int skip = SKIP == 1 ? 2 : SKIP;
-    constexpr int P0_IDS = SKIP == 1 ? 3 : 2;      // which ids the P0 tiles' rows follow (2: source, 3: destination)
-    constexpr int P0_HALF = SKIP == 1 ? 1 : 0;     // the half of the weights (and the row scales) of the P0 phase
-    constexpr bool P0_NT = GHF_BX_NT != 0 && SKIP != 1;   // (a destination row is gathered once per in-edge: default cache policy)
+    // its gathers were issued behind the fold and waited for at the next chunk's start (2.41 -> 2.34 ms per C3 launch, same box,
+    // GHF_VARIANT=bxSWAP10 for the old form; the 4.8 ms of round 2's training profile was this launch beside the weight
+    // gradients' kernel on a second stream)
+    constexpr bool SWAP1 = SKIP == 1 && GHF_BX_SWAP1;
+    constexpr int skip = SWAP1 ? 2 : SKIP;
+    constexpr int P0_IDS = SWAP1 ? 3 : 2;          // which ids the P0 tiles' rows follow (2: source, 3: destination)
+    constexpr int P0_HALF = SWAP1 ? 1 : 0;         // the half of the weights (and the row scales) of the P0 phase
+    constexpr bool P0_NT = GHF_BX_NT != 0 && !SWAP1;   // (a destination row is gathered once per in-edge: default cache policy)
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, NPW = C::NPW;
     constexpr bool DEFER = D == 64 ? (GHF_BX64_DEFER != 0) : (GHF_BX_DEFER != 0);
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
