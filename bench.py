@@ -165,6 +165,24 @@ def cpu_baseline(cfg, budget_s=12.0, full=None):
     return res
 
 
+def roofline_note(wide: bool, plan, d: int) -> str:
+    """What the roofline figures of this workload's dominant kernel mean (which bound is the real one)."""
+    head = "judged against HBM as BASELINE asks; "
+    if wide:
+        return head + ("the relation-stationary layer: pass 0 (runs' source rows summed) and pass 2 (segment sums + tail) are gather / stream "
+                       "bound, pass 1 gathers both rows of every run AND does three fp16 products per flop on one wave per SIMD (293 "
+                       "registers) — at BASELINE config 5 it runs at ~75 % of the dense fp16 matrix peak (DESIGN.md §3, message_rs)")
+    if plan.wlayout == _native.WLAYOUT_SPLIT2H and d == 128:
+        return head + ("the block kernel is bound inside the CU: the vector-memory return path (TD) is busy ~80 % of the launch — a "
+                       "relation's weights re-streamed from L2 per (block, relation) chunk plus the gathered rows, half of it waiting for "
+                       "L2 / Infinity-Cache data — and the matrix pipe ~34 % (profiles/r03_message_kernel_pipes.json, DESIGN.md §3)")
+    if plan.wlayout == _native.WLAYOUT_SPLIT2H:
+        return head + ("hidden 64: a quarter of the matrix work per row, so the fixed cost per (block, relation) chunk — barrier, "
+                       "hand-shakes, descriptor pipeline, two DMA round trips: ~7 k cycles — decides; two workgroups per CU overlap "
+                       "their chains (DESIGN.md §3, Hidden 64)")
+    return head + "a graph this small is one launch latency per kernel: see the HIP-graph replay line (bench.py --hip-graph)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -410,10 +428,7 @@ def main():
                         "bytes_per_launch": l2_bytes, "achieved": l2_bytes / (k_ms * 1e-3) / 1e9,
                         "ceiling": L2_STREAM_CEILING_GBS, "unit": "GB/s",
                         "source": "TCC_REQ_sum x 128 B (same PMC file); ceiling measured by tools/micro/l2stream.hip"},
-                    "note": "judged against HBM as BASELINE asks; the block kernel is bound inside the CU: the vector-memory return "
-                            "path (TD) is busy ~80 % of the launch — a relation's weights re-streamed from L2 per (block, relation) chunk "
-                            "plus the gathered rows, half of it waiting for L2 / Infinity-Cache data — and the matrix pipe ~34 % "
-                            "(profiles/r03_message_kernel_pipes.json, DESIGN.md §3)"}
+                    "note": roofline_note(wide, plan, d)}
         line = {
             "metric": "edges/s (HyperGNN forward)", "value": E / (ms_step * 1e-3), "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
