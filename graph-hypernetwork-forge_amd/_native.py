@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 GHF_FLAG_ZERO_SRC = 4
@@ -76,6 +76,7 @@ SIGNATURES = {
     "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
     "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "ghf_edge_outer_scaled": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "ghf_add3": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -623,10 +624,17 @@ def group_outer(A: Optional[torch.Tensor], ia: Optional[torch.Tensor], B: torch.
     return out
 
 
+def split_row_scales(split: torch.Tensor, N: int, d: int) -> torch.Tensor:
+    """The N row scales (float32 view, no copy) behind the N rows of a SPLIT2H split form (split_rows / alloc_split)."""
+    return split.view(torch.float32)[N * d:N * d + N]
+
+
 def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, slice_tab: torch.Tensor,
-               slice_off: torch.Tensor, R: int, exact: bool = False):
+               slice_off: torch.Tensor, R: int, exact: bool = False, h_scales: Optional[torch.Tensor] = None,
+               G_scales: Optional[torch.Tensor] = None):
     """(dW [R, 2d, d] = dW_msg stacked on dW_self, db [R, d]) of include/ghf.h: ghf_edge_outer (exact: the fp32 chain at
-    every d — a step that fell back to the exact kernels)."""
+    every d — a step that fell back to the exact kernels).  h_scales / G_scales: the row scales of the two tensors' split
+    forms (split_row_scales), when the caller holds them: ghf_edge_outer_scaled, same bits without the pass over h and G."""
     lib = load()
     h, G = _req(h, torch.float32, "h"), _req(G, torch.float32, "G")
     d, ns = h.size(1), slice_tab.size(0)
@@ -634,9 +642,17 @@ def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.T
     ws = torch.empty(ns * (2 * D * D + D) + 64, dtype=torch.float32, device=h.device)
     dW = torch.empty(R, 2 * d, d, dtype=torch.float32, device=h.device)
     db = torch.empty(R, d, dtype=torch.float32, device=h.device)
-    _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), _ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")),
-                              _ptr(_req(slice_tab, torch.int64, "slice_tab")), _ptr(_req(slice_off, torch.int64, "slice_off")),
-                              ns, R, d, 0 if exact else h.size(0), _ptr(ws), _ptr(dW), _ptr(db), _stream()), "ghf_edge_outer")
+    tabs = (_ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")), _ptr(_req(slice_tab, torch.int64, "slice_tab")),
+            _ptr(_req(slice_off, torch.int64, "slice_off")))
+    if not exact and h_scales is not None and G_scales is not None and h.size(0) > 0:
+        hsc, gsc = _req(h_scales, torch.float32, "h_scales"), _req(G_scales, torch.float32, "G_scales")
+        if hsc.numel() != h.size(0) or gsc.numel() != G.size(0):
+            raise ValueError("edge_outer: one row scale per row of h and of G expected")
+        _check(lib.ghf_edge_outer_scaled(_ptr(h), _ptr(G), _ptr(hsc), _ptr(gsc), *tabs, ns, R, d, h.size(0), _ptr(ws), _ptr(dW),
+                                         _ptr(db), _stream()), "ghf_edge_outer_scaled")
+    else:
+        _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), *tabs, ns, R, d, 0 if exact else h.size(0), _ptr(ws), _ptr(dW), _ptr(db),
+                                  _stream()), "ghf_edge_outer")
     return dW, db
 
 

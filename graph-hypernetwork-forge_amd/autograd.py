@@ -172,6 +172,7 @@ class MessageLayerFn(torch.autograd.Function):
         h = h.contiguous()
         W, W2 = _layer_weights(plan, W_msg.detach(), W_self.detach(), transpose=False)
         out = torch.empty_like(h)
+        h_scales = None
         if drop is None and _native.side_output_supported(plan, h.size(1)):   # one launch: h', the aggregate, the next layer's split rows
             agg = torch.empty_like(h)
             hs = tp.carry.take(h)
@@ -181,11 +182,14 @@ class MessageLayerFn(torch.autograd.Function):
             _native.message_layer_fwd(h, plan, W, W2, bias.detach().contiguous(), plan.wlayout, gamma.detach(), beta.detach(), eps,
                                       out, h_split=hs, h_split_out=hs_out, agg_out=agg)
             tp.carry.put(out, hs_out)
+            if plan.wlayout == _native.WLAYOUT_SPLIT2H:
+                # 4 bytes per row: the weight gradients read their scale for h off these (ghf_edge_outer_scaled)
+                h_scales = _native.split_row_scales(hs, h.size(0), h.size(1)).clone()
         else:
             agg = _message(h, plan, W, W2, bias.detach().contiguous(), _native.GHF_FLAG_NO_TAIL)
             _native.tail_fwd(agg, h, gamma.detach(), beta.detach(), eps, out, drop=drop)
         ctx.save_for_backward(h, agg, W_msg, W_self, gamma)
-        ctx.tp, ctx.eps, ctx.drop = tp, eps, drop
+        ctx.tp, ctx.eps, ctx.drop, ctx.h_scales = tp, eps, drop, h_scales
         return out
 
     @staticmethod
@@ -200,6 +204,9 @@ class MessageLayerFn(torch.autograd.Function):
         dpre, G, Gs, dgamma, dbeta = _native.tail_bwd(g, agg, h, gamma.detach(), ctx.eps, plan.indeg, drop=ctx.drop,
                                                       split_layout=plan.wlayout if split_G else None)
         side = None
+        scales = {}
+        if Gs is not None and ctx.h_scales is not None and plan.wlayout == _native.WLAYOUT_SPLIT2H:
+            scales = dict(h_scales=ctx.h_scales, G_scales=_native.split_row_scales(Gs, G.size(0), G.size(1)))
         if tp.slice_tab is not None:
             if _EO_SIDE and ctx.needs_input_grad[0]:
                 # the weight gradients (bound by their row gathers) beside the two gradient passes (bound inside the CU): two
@@ -208,9 +215,9 @@ class MessageLayerFn(torch.autograd.Function):
                 side = _side_stream(h.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact)
+                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact, **scales)
             else:
-                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact)
+                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact, **scales)
             d = h.size(1)
             dWm, dWs = dW[:, :d], dW[:, d:]
         else:

@@ -581,6 +581,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + blockIdx.y, __float_as_uint(m));   // (non-negative floats order as their bits)
 }
 
+// The same two words from the row scales of the tensors' split forms (ghf_split_rows: one float 2^-s(row) per row, s =
+// split2h_shift(the row's largest magnitude)): 2^13 max_row 2^-s(row) = 2^e of the tensor's largest magnitude — the one thing
+// edge_outer_h_kernel takes from its maximum (split2h_shift reads the exponent only).  n floats per tensor instead of n d.
+__global__ __launch_bounds__(256) void rowscale_absmax_kernel(const float* __restrict__ s0, const float* __restrict__ s1, int64_t n,
+                                                              unsigned* __restrict__ out) {
+    const float* __restrict__ sc = blockIdx.y ? s1 : s0;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, sc[i]);
+    m = wave_absmax(m) * 8192.0f;
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + blockIdx.y, __float_as_uint(m));
+}
+
 __device__ __forceinline__ unsigned eo_off(int row, int ch) { return 256u * row + 16u * (unsigned)(ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 __global__ __launch_bounds__(512) void edge_outer_h_kernel(
@@ -766,7 +778,7 @@ int edge_outer_supported(int d) { return d == 64 || (d >= 128 && d <= BW_MAX_D &
 
 int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                       const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db,
-                      hipStream_t stream) {
+                      hipStream_t stream, const float* h_rowscale, const float* G_rowscale) {
     GHF_REQUIRE(edge_outer_supported(d), "edge_outer: d = %d has no tile (64 and multiples of 128 do; use ghf_group_outer)", d);
     GHF_REQUIRE(nslices > 0 && R > 0, "edge_outer: nothing to do");
     const int D = d == 64 ? 64 : 128;                      // tile: [2D, D] of the relation's [2d, d] gradient
@@ -779,8 +791,13 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
     const bool pieces = D == 128 && !exact && N > 0;      // (N <= 0: the caller asks for the exact fp32 chain, ghf.h)
     if (pieces) {
         GHF_HIP_CHECK(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), stream));
-        const unsigned ag = (unsigned)(cdiv(N * d, 256 * 16) < 2048 ? cdiv(N * d, 256 * 16) : 2048);
-        absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h, G, N * d, amax);
+        if (h_rowscale && G_rowscale) {                    // the caller holds both tensors' split forms: their row scales say it
+            const unsigned ag = (unsigned)(cdiv(N, 256 * 4) < 1024 ? cdiv(N, 256 * 4) : 1024);
+            rowscale_absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h_rowscale, G_rowscale, N, amax);
+        } else {
+            const unsigned ag = (unsigned)(cdiv(N * d, 256 * 16) < 2048 ? cdiv(N * d, 256 * 16) : 2048);
+            absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h, G, N * d, amax);
+        }
         GHF_LAUNCH_CHECK();
     }
     for (int rb = 0; rb < d / D; ++rb)                     // tile rows 2D*rb ..: two D-column pieces of [h_src | h_dst]

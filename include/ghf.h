@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 12
+#define GHF_ABI_VERSION 13
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -304,6 +304,13 @@ int ghf_edge_outer_supported(int d);
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                    const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N /* rows of h and G */, float* workspace,
                    float* dW, float* db, void* stream);
+/* The same for a caller that holds the split forms of h and G (ghf_split_rows / the h_split_out of a layer / ghf_tail_bwd's
+ * G_split): h_rowscale, G_rowscale [N] = their row scales (the N floats behind the N split rows).  The one scale per tensor is
+ * then read off those (2^13 max_row 2^-s(row) has the exponent of the tensor's largest magnitude) instead of by a pass over
+ * both tensors: same pieces, same products, same bits as ghf_edge_outer with N > 0.  N > 0 required. */
+int ghf_edge_outer_scaled(const float* h, const float* G, const float* h_rowscale, const float* G_rowscale, const int64_t* src,
+                          const int64_t* dst, const int64_t* slice_tab, const int64_t* slice_off, int64_t nslices, int R, int d,
+                          int64_t N, float* workspace, float* dW, float* db, void* stream);
 /* Elementwise pieces of the backward: out = X * exp(log_scale[0]) (log_scale on the device: the generator's learnable
  * scale, reference weight_generator.py:137-141); out = a + b (+ c when non-NULL); out[i][:] = g[i] * X[i][:] (the two
  * gradients of score_triple, reference hypergnn.py:304-318).  out may alias an input. */

@@ -39,7 +39,7 @@ def test_native_library_is_loaded():
     assert lib.ghf_abi_version() == _native.ABI_VERSION
     assert os.path.basename(_native.lib_path()) == "libghf_hip.so"
     assert _native.message_config(128) == (384, _native.WLAYOUT_SPLIT2H, 76, 128)
-    assert _native.message_config(64) == (256, _native.WLAYOUT_SPLIT2H, 112, 128)
+    assert _native.message_config(64) == (192, _native.WLAYOUT_SPLIT2H, 64, 128)
     assert _native.message_config(20) == (1, _native.WLAYOUT_NATURAL, 0, 0)
     try:
         os.environ["GHF_KERNEL"] = "pp"
@@ -656,6 +656,17 @@ def test_edge_outer_matches_the_plain_contraction(d, N, E, R):
     dW, db = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
     again = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
     assert torch.equal(dW, again[0]) and torch.equal(db, again[1])   # fixed summation order
+    if d % 128 == 0:
+        # ghf_edge_outer_scaled: the one scale per tensor read off the row scales of the split forms — the same bits
+        # (rows scaled apart by 2^20 and a row of zeros: the tensor's scale is its largest row's)
+        h2 = h.copy()
+        h2[3] *= 2.0 ** 20
+        h2[5] = 0.0
+        hs, gs = _native.split_rows(t(h2), _native.WLAYOUT_SPLIT2H), _native.split_rows(t(G), _native.WLAYOUT_SPLIT2H)
+        plain = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
+        scaled = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R,
+                                    h_scales=_native.split_row_scales(hs, N, d), G_scales=_native.split_row_scales(gs, N, d))
+        assert torch.equal(plain[0], scaled[0]) and torch.equal(plain[1], scaled[1])
     h64, G64 = h.astype(np.float64), G.astype(np.float64)
     for r in range(R):
         m = rel == r
