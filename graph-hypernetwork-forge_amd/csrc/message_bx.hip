@@ -148,6 +148,12 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_NOSLEEP
 #define GHF_BX_NOSLEEP 0      // diagnostics
 #endif
+#ifndef GHF_BX_PAUSE16
+#define GHF_BX_PAUSE16 1      // what a failed poll of the consumers' staging flags does (see wait_flags)
+#endif
+#ifndef GHF_BX_PAUSE0
+#define GHF_BX_PAUSE0 1       // ... of the helpers' fold flags
+#endif
 #ifndef GHF_BX_NT
 #define GHF_BX_NT 1           // 1: the source-row gathers are non-temporal loads (each row is read once per block and relation)
 #endif
@@ -206,6 +212,37 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
 // Diagnostic build (-DGHF_BX_CHECK): consumer wave 0 compares the A tiles in LDS with the rows they should hold (granule slot 0
 // of every live row, both planes) before and after each phase; mismatches go here: [0] = count, then 8 ints per record.
 __device__ int ghf_bx_check_buf[8 + 8 * 8192];
+// the chunk barrier itself: every wave writes the chunk it is about to wait for into its word of the scratch KiB (DUMMY_OFF:
+// unused where RBN % 4 == 0) and, past the barrier, expects all eight words to have reached that chunk (records: code 12)
+#define BX_BAR_ARRIVE(kk)                                                                                   \
+    do {                                                                                                    \
+        if (lane == 0) lds_st_b32(lds0 + DUMMY_OFF + 4 * w, (kk) + 1);                                      \
+        BX_LGKM0();                                                                                         \
+    } while (0)
+#define BX_BAR_INIT()                                                                                       \
+    do {                                                                                                    \
+        if (lane == 0) lds_st_b32(lds0 + DUMMY_OFF + 4 * w, 0);                                             \
+        BX_LGKM0();                                                                                         \
+    } while (0)
+#define BX_BAR_VERIFY(kk)                                                                                   \
+    do {                                                                                                    \
+        int _m = (kk) + 1, _who = -1;                                                                       \
+        for (int _i = 0; _i < 8; ++_i) {                                                                    \
+            const int _a = *(const volatile int*)(smem + DUMMY_OFF + 4 * _i);                               \
+            if (_a < _m) { _m = _a; _who = _i; }                                                            \
+        }                                                                                                   \
+        if (_who >= 0 && lane == 0) {                                                                       \
+            const int _s = atomicAdd(&ghf_bx_check_buf[0], 1);                                              \
+            if (_s < 8192) {                                                                                \
+                int* _o = ghf_bx_check_buf + 8 + 8 * _s;                                                    \
+                _o[0] = (int)blk; _o[1] = (kk); _o[2] = w; _o[3] = 12 * 16; _o[4] = _who; _o[5] = _m; _o[6] = nchunks; _o[7] = 0; \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+#else
+#define BX_BAR_ARRIVE(kk)
+#define BX_BAR_VERIFY(kk)
+#define BX_BAR_INIT()
 #endif
 
 template <int D> struct BxCfg;
@@ -686,17 +723,21 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             }
         };
         // wait until all four words at `flags` have reached v (the waves of one role run the same program: short waits)
-        auto wait_flags = [&](unsigned flags, int v) {
+        // (pause_c: what a failed poll does — 1: s_sleep 1; 0: poll again at once; 2: 64 cycles of s_nop.  GHF_BX_PAUSE16 /
+        //  GHF_BX_PAUSE0 choose it for the two waits of a chunk: diagnostics of DESIGN.md's "unexplained hazard")
+        auto wait_flags = [&](unsigned flags, int v, auto pause_c) {
+            constexpr int PAUSE = decltype(pause_c)::value;
             for (;;) {
                 i32x4 f;
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(flags) : "memory");
                 const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (__builtin_amdgcn_readfirstlane(lo) >= v) break;
-#if !GHF_BX_NOSLEEP
-                __builtin_amdgcn_s_sleep(1);
-#endif
+                if constexpr (PAUSE == 1) __builtin_amdgcn_s_sleep(1);
+                if constexpr (PAUSE == 2) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             }
         };
+        using pause16_t = std::integral_constant<int, GHF_BX_NOSLEEP ? 0 : GHF_BX_PAUSE16>;
+        using pause0_t = std::integral_constant<int, GHF_BX_NOSLEEP ? 0 : GHF_BX_PAUSE0>;
 
         // ---- one workgroup barrier per chunk.  During chunk k (between barriers k and k + 1):
         //   consumers: phase 0 from P0[k&1], phase 1 from P1[k&1]; once all four have read that tile, the chunk's rows Y(k)
@@ -734,6 +775,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             scP = sc[2];
             wdN = wd[3];
         }
+        BX_BAR_INIT();
         BX_LGKM0();
         __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0 and 1 visible to all helper waves
         // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
@@ -748,7 +790,9 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         int sid[6] = {0, 0, 0, 0, 0, 0};                   // source ids of the NEXT chunk's rows (read at the end of a chunk)
         if (nchunks > 0 && !(skip & 1)) dma_ids(1, P0_IDS, lane, sid);
         for (int k = 0; k < nchunks; ++k) {
+            BX_BAR_ARRIVE(k);
             __builtin_amdgcn_s_barrier();                  // ---- chunk k
+            BX_BAR_VERIFY(k);
             BX_STAMP(0);
             const int l0 = opaque_lane(lane);
             if (k > 0) {                                   // everything requested during the last chunk has arrived
@@ -776,11 +820,11 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
 #if GHF_BX_PLANLATE
-                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);
+                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k, pause16_t{});
                 const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
 #else
                 const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
-                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
+                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k, pause16_t{});   // all four consumer waves have staged Y(k-1)
 #endif
                 BX_STAMP(5);                               // (stamps: the wait for the staged rows)
                 fold_rows(k - 1, fp, l0);
@@ -793,7 +837,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             BX_STAMP(2);
             // without a tile of their own the staged rows sit where the next destination rows go: every helper wave must have
             // folded them first
-            wait_flags(lds0 + FLAG_OFF, k + 1);
+            wait_flags(lds0 + FLAG_OFF, k + 1, pause0_t{});
             BX_STAMP(3);
             const int l1 = opaque_lane(lane);
             // the next requests of the descriptor pipeline: behind the loops above (a load in flight across a loop makes hipcc
@@ -1044,7 +1088,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 }
             }
         };
-#define BX_CHECK(tile, which, code) check_tile(tile, which, meta, ch, k, code)
+#define BX_CHECK(tile, which, code) do { if (GHF_BX_CHECK >= 2) check_tile(tile, which, meta, ch, k, code); } while (0)
 #else
 #define BX_CHECK(tile, which, code)
 #endif
@@ -1067,11 +1111,14 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
             for (int j = 0; j < KS; ++j) load_b_step(ch.r, ph_first, j);
         }
+        BX_BAR_INIT();
         __syncthreads();                                   // barrier A
         for (int k = 0; k < nchunks; ++k) {
             const int mt = (ch.rows + 15) >> 4;
             const int* meta = (const int*)(smem + meta_off(k));
+            BX_BAR_ARRIVE(k);
             __syncthreads();                               // ---- chunk k
+            BX_BAR_VERIFY(k);
             BX_STAMP(0);
             constexpr bool PRE_OK = skip == 0 && !YT && GHF_BX_LATE;
             constexpr bool PRE0 = (GHF_BX_PRE & 1) && PRE_OK, PRE1 = (GHF_BX_PRE & 2) && PRE_OK;      // first / second phase

@@ -30,8 +30,12 @@ for i in range(runs):
     assert fn(buf.ctypes.data, buf.size, 1) == 0
     n = int(buf[0])
     rec = buf[8:8 + 8 * min(n, 8192)].reshape(-1, 8)
-    idrec = rec[(rec[:, 3] >> 4) >= 8]
+    barrec = rec[(rec[:, 3] >> 4) == 12]
+    idrec = rec[((rec[:, 3] >> 4) >= 8) & ((rec[:, 3] >> 4) != 12)]
     rec = rec[(rec[:, 3] >> 4) < 8]
+    print(f"run {i}: {len(barrec)} waves were past a chunk barrier before another wave had reached it")
+    for blk, k, w_, code, who, seen, nch, _ in barrec.tolist()[:24]:
+        print(f"      barrier: blk {blk} chunk {k} of {nch}: wave {w_} is past it, wave {who} had only announced chunk {seen - 1}")
     print(f"run {i}: {len(rec)} mismatching (row, plane) tile checks, {len(idrec)} ids wrong at DMA issue")
     for blk, k, r, code, got, want, hw, nrow in idrec.tolist()[:24]:
         print(f"      ids at issue: blk {blk} chunk {k} ({'src' if (code >> 2) & 3 == 2 else 'dst'}) row {r} of {nrow}, helper {hw}: id {got} want {want}")

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--kind", default="uniform", choices=["uniform", "powerlaw"])
     ap.add_argument("--score", default="triple", choices=["triple", "edges"],
                     help="the loss's scores: score_triple(embs[src], embs[dst]) as in the reference's demo, or the fused score_edges")
+    ap.add_argument("--freeze-generators", action="store_true",
+                    help="diagnostics: no gradients for the weight generators' parameters (what their backward costs per step)")
     args = ap.parse_args()
     from graph_hypernetwork_forge_amd import HyperGNN, _native, synth
     _native.load()
@@ -45,6 +47,10 @@ def main():
     x = torch.randn(N, d, generator=torch.Generator(device=dev).manual_seed(1), device=dev)
     torch.manual_seed(0)
     model = HyperGNN(text_dim=T, node_feat_dim=d, hidden_dim=d, num_layers=L).to(dev).train()
+    if args.freeze_generators:
+        for n_, p_ in model.named_parameters():
+            if "weight_generators" in n_ or "text_encoder" in n_:
+                p_.requires_grad_(False)
     src, dst = edge_index[0, :1_000_000], edge_index[1, :1_000_000]
     perm = torch.randperm(dst.numel(), device=dev)
 
