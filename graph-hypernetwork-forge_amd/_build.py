@@ -25,7 +25,7 @@ import re as _re
 if "stamps" in VARIANT:
     FLAGS.append("-DGHF_STAMPS")
 if "bxcheck" in VARIANT:                                # "bxcheck2": the tile checks too (they slow the consumers)
-    FLAGS.append("-DGHF_BX_CHECK=2" if "bxcheck2" in VARIANT else "-DGHF_BX_CHECK=1")                      # message_bx.hip: tiles verified against the rows they should hold
+    FLAGS.append("-DGHF_BX_CHECK=3" if "bxcheck3" in VARIANT else "-DGHF_BX_CHECK=2" if "bxcheck2" in VARIANT else "-DGHF_BX_CHECK=1")   # 3: an LDS canary only                      # message_bx.hip: tiles verified against the rows they should hold
 if VARIANT == "ablate":
     FLAGS.append("-DGHF_ABLATE")
 _b = _re.search(r"baux(\d+)", VARIANT)

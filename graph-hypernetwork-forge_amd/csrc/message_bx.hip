@@ -212,6 +212,8 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
 // Diagnostic build (-DGHF_BX_CHECK): consumer wave 0 compares the A tiles in LDS with the rows they should hold (granule slot 0
 // of every live row, both planes) before and after each phase; mismatches go here: [0] = count, then 8 ints per record.
 __device__ int ghf_bx_check_buf[8 + 8 * 8192];
+#endif
+#if defined(GHF_BX_CHECK) && GHF_BX_CHECK < 3
 // the chunk barrier itself: every wave writes the chunk it is about to wait for into its word of the scratch KiB (DUMMY_OFF:
 // unused where RBN % 4 == 0) and, past the barrier, expects all eight words to have reached that chunk (records: code 12)
 #define BX_BAR_ARRIVE(kk)                                                                                   \
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 }
             }
         };
-#ifdef GHF_BX_CHECK
+#if defined(GHF_BX_CHECK) && GHF_BX_CHECK < 3
         // the ids a DMA is about to use, against the edge arrays (records: code 8 + which)
         auto check_ids = [&](const BxChunk& c, int which, int kk, int lane, const int (&id)[6]) {
 #pragma unroll
@@ -756,6 +758,10 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (lane + 64 * i < 128 + 16) lds_st_b32(lds0 + ZERO_OFF + 4 * (lane + 64 * i), 0);
+#if defined(GHF_BX_CHECK) && GHF_BX_CHECK >= 3               // canary: 240 words of the scratch KiB that nothing may touch
+        if (hw == 0)
+            for (int i = lane; i < 240; i += 64) lds_st_b32(lds0 + DUMMY_OFF + 64 + 4 * i, (int)0xC0FFEE00 + i);
+#endif
         int prev_rows = 1;
         if (nchunks > 0) {
             i32x2 dd[5];
@@ -870,6 +876,19 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
         BX_LGKM0();
         BX_STAMP(5);
+#if defined(GHF_BX_CHECK) && GHF_BX_CHECK >= 3
+        if (hw == 1)
+            for (int i = lane; i < 240; i += 64) {
+                const int got = *(const volatile int*)(smem + DUMMY_OFF + 64 + 4 * i);
+                if (got != (int)0xC0FFEE00 + i) {
+                    const int slot_i = atomicAdd(&ghf_bx_check_buf[0], 1);
+                    if (slot_i < 8192) {
+                        int* o = ghf_bx_check_buf + 8 + 8 * slot_i;
+                        o[0] = (int)blk; o[1] = nchunks; o[2] = i; o[3] = 13 * 16; o[4] = got; o[5] = (int)0xC0FFEE00 + i; o[6] = 0; o[7] = 0;
+                    }
+                }
+            }
+#endif
         if constexpr (D == 128) asm volatile("" : BX_PIN_128(sm)); else asm volatile("" : BX_PIN_64(sm));
         // dump row HPW*hw + i = node NPW*hw + HPW*half + i, natural column order: position PL*lane + e is column
         // 32 (lane / 16) + 16 e + lane % 16 at d = 128 (a consumer wave's two fragments, interleaved), column lane at d = 64
@@ -1088,7 +1107,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 }
             }
         };
-#define BX_CHECK(tile, which, code) do { if (GHF_BX_CHECK >= 2) check_tile(tile, which, meta, ch, k, code); } while (0)
+#define BX_CHECK(tile, which, code) do { if (GHF_BX_CHECK == 2) check_tile(tile, which, meta, ch, k, code); } while (0)
 #else
 #define BX_CHECK(tile, which, code)
 #endif

@@ -31,7 +31,11 @@ for i in range(runs):
     n = int(buf[0])
     rec = buf[8:8 + 8 * min(n, 8192)].reshape(-1, 8)
     barrec = rec[(rec[:, 3] >> 4) == 12]
-    idrec = rec[((rec[:, 3] >> 4) >= 8) & ((rec[:, 3] >> 4) != 12)]
+    canary = rec[(rec[:, 3] >> 4) == 13]
+    print(f"run {i}: {len(canary)} canary words of the scratch KiB changed")
+    for blk, nch, idx, code, got, want, _, _ in canary.tolist()[:40]:
+        print(f"      canary: blk {blk} ({nch} chunks) word {idx}: {got & 0xffffffff:08x} (was {want & 0xffffffff:08x})")
+    idrec = rec[((rec[:, 3] >> 4) >= 8) & ((rec[:, 3] >> 4) < 12)]
     rec = rec[(rec[:, 3] >> 4) < 8]
     print(f"run {i}: {len(barrec)} waves were past a chunk barrier before another wave had reached it")
     for blk, k, w_, code, who, seen, nch, _ in barrec.tolist()[:24]:
