@@ -167,6 +167,7 @@ def cpu_baseline(cfg, budget_s=12.0, full=None):
 
 def roofline_note(wide: bool, plan, d: int) -> str:
     """What the roofline figures of this workload's dominant kernel mean (which bound is the real one)."""
+    from graph_hypernetwork_forge_amd import _native
     head = "judged against HBM as BASELINE asks; "
     if wide:
         return head + ("the relation-stationary layer: pass 0 (runs' source rows summed) and pass 2 (segment sums + tail) are gather / stream "
