@@ -142,6 +142,15 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_SWAP1
 #define GHF_BX_SWAP1 1        // 0 (A/B): ZERO_SRC as a second phase without a first one, as in round 2
 #endif
+#ifndef GHF_BX_DRAIN
+#define GHF_BX_DRAIN 0        // diagnostics
+#endif
+#ifndef GHF_BX_ASMWAIT
+#define GHF_BX_ASMWAIT 0      // diagnostics (see wait_flags)
+#endif
+#ifndef GHF_BX_FOLD2
+#define GHF_BX_FOLD2 0        // diagnostics (see fold_plan)
+#endif
 #ifndef GHF_BX_PLANLATE
 #define GHF_BX_PLANLATE 0     // diagnostics
 #endif
@@ -212,6 +221,25 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
 // Diagnostic build (-DGHF_BX_CHECK): consumer wave 0 compares the A tiles in LDS with the rows they should hold (granule slot 0
 // of every live row, both planes) before and after each phase; mismatches go here: [0] = count, then 8 ints per record.
 __device__ int ghf_bx_check_buf[8 + 8 * 8192];
+#endif
+// GHF_BX_CHECK == 4: every flag wait gives up after 2^20 polls, records (block, wave, site, chunk, the four flag words) — code 14 —
+// and goes on (the launch then ends, with wrong results, instead of hanging)
+#if defined(GHF_BX_CHECK) && GHF_BX_CHECK == 4
+#define BX_SPIN_DECL int _spins = 0
+#define BX_SPIN_GIVE_UP(site, kk, f)                                                                        \
+    if (++_spins > (1 << 20)) {                                                                             \
+        if (lane == 0) {                                                                                    \
+            const int _s = atomicAdd(&ghf_bx_check_buf[0], 1);                                              \
+            if (_s < 8192) {                                                                                \
+                int* _o = ghf_bx_check_buf + 8 + 8 * _s;                                                    \
+                _o[0] = (int)blk; _o[1] = (kk); _o[2] = w; _o[3] = 14 * 16 + (site); _o[4] = f[0]; _o[5] = f[1]; _o[6] = f[2]; _o[7] = f[3]; \
+            }                                                                                               \
+        }                                                                                                   \
+        break;                                                                                              \
+    }
+#else
+#define BX_SPIN_DECL
+#define BX_SPIN_GIVE_UP(site, kk, f)
 #endif
 #if defined(GHF_BX_CHECK) && GHF_BX_CHECK < 3
 // the chunk barrier itself: every wave writes the chunk it is about to wait for into its word of the scratch KiB (DUMMY_OFF:
@@ -647,6 +675,27 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         // destination and second source of the adds relative to it (mode 0xa), base register v64.  M0 also holds the LDS
         // base of the wave's LDS-DMA instructions: saved and restored around the mode.  Steps past cnt read the row of
         // zeros into node 0 (no branch inside a step).
+#if GHF_BX_FOLD2
+        // (diagnostics: the one-readlane fold of DESIGN.md's hazard record — m0 / m1: lane j holds the sum-register index of MY
+        //  row number j / 64 + j, 0 behind my last row)
+        struct FoldPlan { int n0, n1, ra, cnt; };
+        auto fold_plan = [&](int j, int rows, int lane) __attribute__((always_inline)) -> FoldPlan {
+            const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
+            int d0, d1;
+            lds_ld_b32_x2(dd + 4 * lane, dd + 4 * (lane + 64 < CRP ? lane + 64 : CRP - 1), d0, d1);
+            const int base = (int)node0 + hw * NPW;
+            const int n0 = d0 - base, n1 = d1 - base;
+            const unsigned long long q0 = __ballot(lane < rows && (unsigned)n0 < (unsigned)NPW);
+            const unsigned long long q1 = __ballot(lane + 64 < rows && (unsigned)n1 < (unsigned)NPW);
+            const int cnt = __builtin_popcountll(q0) + __builtin_popcountll(q1);
+            const int ra = q0 ? (int)__builtin_ctzll(q0) : 64 + (q1 ? (int)__builtin_ctzll(q1) : 0);
+            const int src = 4 * ((ra + lane) & 63);
+            const int a = __builtin_amdgcn_ds_bpermute(src, n0), b = CRP > 64 ? __builtin_amdgcn_ds_bpermute(src, n1) : 0;
+            const int m0 = lane < cnt ? PL * (ra + lane < 64 ? a : b) : 0;
+            const int m1 = (CRP > 64 && lane + 64 < cnt) ? PL * b : 0;
+            return FoldPlan{m0, m1, ra, cnt};
+        };
+#else
         struct FoldPlan { int n0, n1, ra, cnt; };
         // which of chunk j's rows are mine (one LDS round trip; taken BEFORE the wait for the staged rows: the descriptor has
         // long been published)
@@ -662,6 +711,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             const int ra = q0 ? (int)__builtin_ctzll(q0) : 64 + (q1 ? (int)__builtin_ctzll(q1) : 0);
             return FoldPlan{n0, n1, ra, cnt};
         };
+#endif
         auto fold_rows = [&](int j, const FoldPlan& fp, int lane) __attribute__((always_inline)) {
             const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
             const int ra = fp.ra, cnt = fp.cnt;
@@ -690,12 +740,18 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 if (behind) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
                 int ix[FB];
+#if GHF_BX_FOLD2
+                const int msel = (CRP > 64 && r0 >= 64) ? fp.n1 : fp.n0;
+#pragma unroll
+                for (int i = 0; i < FB; ++i) ix[i] = __builtin_amdgcn_readlane(msel, (r0 + i) & 63);
+#else
 #pragma unroll
                 for (int i = 0; i < FB; ++i) {                           // the row's node: lane (row mod 64) of n0 or n1 (both read: no branch)
                     const int rr = ra + r0 + i;
                     const int a = __builtin_amdgcn_readlane(fp.n0, rr & 63), b = __builtin_amdgcn_readlane(fp.n1, rr & 63);
                     ix[i] = r0 + i < cnt ? PL * (rr < 64 ? a : b) : 0;
                 }
+#endif
                 int keep;
 #define BX_ROW128(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_pk_add_f32 v[64:65], %[y" #i "], v[64:65]\n\t"
 #define BX_ROW64(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_add_f32 v64, %[y" #i "], v64\n\t"
@@ -729,11 +785,30 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         //  GHF_BX_PAUSE0 choose it for the two waits of a chunk: diagnostics of DESIGN.md's "unexplained hazard")
         auto wait_flags = [&](unsigned flags, int v, auto pause_c) {
             constexpr int PAUSE = decltype(pause_c)::value;
+#if GHF_BX_ASMWAIT
+            // (diagnostics: the whole wait in one asm statement — a compare on SCC, no s_cbranch_vccz)
+            int f0, f1, f2, f3, sres;
+            asm volatile("1:\n\t"
+                         "ds_read_b32 %0, %5\n\tds_read_b32 %1, %5 offset:4\n\tds_read_b32 %2, %5 offset:8\n\tds_read_b32 %3, %5 offset:12\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_min_i32 %0, %0, %1\n\tv_min_i32 %2, %2, %3\n\tv_min_i32 %0, %0, %2\n\t"
+                         "s_nop 1\n\t"
+                         "v_readfirstlane_b32 %4, %0\n\t"
+                         "s_cmp_ge_i32 %4, %6\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_sleep 1\n\t"
+                         "s_branch 1b\n\t"
+                         "2:"
+                         : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&s"(sres) : "v"(flags), "s"(v) : "memory", "scc");
+            return;
+#endif
+            BX_SPIN_DECL;
             for (;;) {
                 i32x4 f;
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(flags) : "memory");
                 const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (__builtin_amdgcn_readfirstlane(lo) >= v) break;
+                BX_SPIN_GIVE_UP((int)((flags - lds0 - FLAG_OFF) >> 4), v, f);
                 if constexpr (PAUSE == 1) __builtin_amdgcn_s_sleep(1);
                 if constexpr (PAUSE == 2) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             }
@@ -813,6 +888,9 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
             if (!(skip & 1) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], P0_IDS, k + 1, l0, sid);
+#if GHF_BX_DRAIN                                           // diagnostics: no two generations of DMAs in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, P0_NT, l0, sid);
             if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1], false, l0);
             if (GHF_BX_LATE && N_DST > 0) {
@@ -1162,11 +1240,13 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             // behind the first phase's k-steps: this chunk's destination rows have landed (helpers' flags) -> the second phase's
             // first fragments are requested before the first phase's unscale
             auto wait_landed = [&]() __attribute__((always_inline)) {
+                BX_SPIN_DECL;
                 for (;;) {
                     i32x4 f;
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 32) : "memory");
                     const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                     if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
+                    BX_SPIN_GIVE_UP(8 + 2, k + 1, f);
                     __builtin_amdgcn_s_sleep(1);
                 }
             };
@@ -1214,11 +1294,13 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 const unsigned fw = DEFER ? FLAG_OFF + 48 : FLAG_OFF + (YT ? 0 : 16);      // (DEFER: words of their own)
                 const int fv = DEFER ? 1 : k + 1;
                 if (!YT && lane == 0) lds_st_b32(lds0 + (DEFER ? FLAG_OFF + 48 : FLAG_OFF + 16) + 4 * tw, fv);
+                BX_SPIN_DECL;
                 for (;;) {
                     i32x4 f;
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + fw) : "memory");
                     const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                     if (__builtin_amdgcn_readfirstlane(lo) >= fv) break;
+                    BX_SPIN_GIVE_UP(8 + (int)((fw - FLAG_OFF) >> 4), fv, f);
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!(GHF_BXEXP & 16)) write_rows(mt, YT ? Y_OFF : P1_OFF + (k & 1) * TILE);

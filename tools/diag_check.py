@@ -31,6 +31,11 @@ for i in range(runs):
     n = int(buf[0])
     rec = buf[8:8 + 8 * min(n, 8192)].reshape(-1, 8)
     barrec = rec[(rec[:, 3] >> 4) == 12]
+    gaveup = rec[(rec[:, 3] >> 4) == 14]
+    print(f"run {i}: {len(gaveup)} flag waits gave up")
+    sites = {0: "helper: fold flags", 1: "helper: staging flags", 10: "consumer: landed flags", 9: "consumer: staging hand-shake", 11: "consumer: last-chunk hand-shake"}
+    for blk, k, w_, code, f0, f1, f2, f3 in gaveup.tolist()[:40]:
+        print(f"      gave up: blk {blk} wave {w_} at {sites.get(code & 15, code & 15)} waiting for {k}: flags {f0} {f1} {f2} {f3}")
     canary = rec[(rec[:, 3] >> 4) == 13]
     print(f"run {i}: {len(canary)} canary words of the scratch KiB changed")
     for blk, nch, idx, code, got, want, _, _ in canary.tolist()[:40]:
