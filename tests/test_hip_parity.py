@@ -1497,7 +1497,8 @@ def test_full_size_c3_layer_properties(N, E, R, d, kernel):
     assert_close(out1[t(rows)].cpu().numpy(), ref.numpy(), f"sampled rows of the {E // 1_000_000}M-edge layer")
 
 
-@pytest.mark.parametrize("N,E,R,d,launches", [(1_000_000, 10_000_000, 64, 128, 25), (500_000, 5_000_000, 32, 64, 100)])
+@pytest.mark.parametrize("N,E,R,d,launches", [(1_000_000, 10_000_000, 64, 128, 25), (500_000, 5_000_000, 32, 64, 100),
+                                              (100_000, 1_000_000, 32, 64, 300)])
 def test_block_kernel_is_bitwise_reproducible_over_many_launches(N, E, R, d, launches, monkeypatch):
     """The two-piece block kernel at full size, launched again and again on the same inputs: every launch must give the first
     one's bits.  (Round 3: hidden 64 runs two workgroups per CU; with the deferred staging of hidden 128 that geometry lost a
