@@ -154,6 +154,40 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_PLANLATE
 #define GHF_BX_PLANLATE 0     // diagnostics
 #endif
+#ifndef GHF_BX_FOLD3
+#define GHF_BX_FOLD3 0        // diagnostics (hidden 64): the fold without the VGPR indexing mode — a select chain over the sums
+#endif
+#ifndef GHF_BX_FOLDDRAIN
+#define GHF_BX_FOLDDRAIN 0    // diagnostics: every row read of a fold step has landed before the indexing mode goes on
+#endif
+#ifndef GHF_BX_FOLDDELAY
+#define GHF_BX_FOLDDELAY 0    // diagnostics: 64-cycle pauses behind every four folded rows (the select-chain fold's pace)
+#endif
+#ifndef GHF_BX_SIDINIT
+#define GHF_BX_SIDINIT 0      // diagnostics: what the source-id registers hold before their first read
+#endif
+#ifndef GHF_BX_SIDLATE
+#define GHF_BX_SIDLATE 0      // diagnostics: the next chunk's source ids read behind the barrier, right before their DMA
+#endif
+#ifndef GHF_BX_IDXWAIT
+#define GHF_BX_IDXWAIT 16     // wait states behind s_set_gpr_idx_on / _off in the fold (0, 1, 2, 4, 8, 16: see add_rows)
+#endif
+#if GHF_BX_IDXWAIT == 0
+#define BX_IDX_WAIT ""
+#elif GHF_BX_IDXWAIT == 1
+#define BX_IDX_WAIT "s_nop 0\n\t"
+#elif GHF_BX_IDXWAIT == 2
+#define BX_IDX_WAIT "s_nop 1\n\t"
+#elif GHF_BX_IDXWAIT == 4
+#define BX_IDX_WAIT "s_nop 3\n\t"
+#elif GHF_BX_IDXWAIT == 8
+#define BX_IDX_WAIT "s_nop 7\n\t"
+#else
+#define BX_IDX_WAIT "s_nop 7\n\ts_nop 7\n\t"
+#endif
+#ifndef GHF_BX_REV
+#define GHF_BX_REV 0          // diagnostics: a tile's DMA pieces issued last piece first
+#endif
 #ifndef GHF_BX_NOSLEEP
 #define GHF_BX_NOSLEEP 0      // diagnostics
 #endif
@@ -620,7 +654,8 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         auto dma_issue = [&](unsigned tile_off, int rows, bool nt, int lane, const int (&id)[6]) {
             if (GHF_BXEXP & 2) return;
 #pragma unroll
-            for (int i = 0; i < RBW; ++i) {
+            for (int i_ = 0; i_ < RBW; ++i_) {
+                const int i = GHF_BX_REV ? RBW - 1 - i_ : i_;
                 const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
                 // (a piece without live rows is issued too when GHF_BX_LATE: every lane past the buffer — zeros, no memory
                 // access — so that the number of DMA instructions per tile is a constant the counted waits can name)
@@ -752,23 +787,50 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                     ix[i] = r0 + i < cnt ? PL * (rr < 64 ? a : b) : 0;
                 }
 #endif
+#if GHF_BX_FOLD3
+                if constexpr (D == 64) {                                 // (diagnostics: no indexing mode, no M0 traffic)
+#pragma unroll
+                    for (int i = 0; i < FB; ++i)
+#pragma unroll
+                        for (int n = 0; n < NPW; ++n) sm[n / TUP][n % TUP] += ix[i] == n ? y[i] : 0.f;
+                    // 2: and M0 rewritten as the real fold rewrites it (no mode); 3: and the mode switched on and off (no VALU
+                    // instruction inside); 4: as 3 with the real fold's instruction count between (index changes, no adds)
+                    int keep2;
+                    if (GHF_BX_FOLD3 == 2)
+                        asm volatile("s_mov_b32 %[kp], m0\n\ts_or_b32 m0, %[i0], 0xa000\n\ts_nop 3\n\ts_or_b32 m0, %[i1], 0xa000\n\ts_nop 3\n\t"
+                                     "s_or_b32 m0, %[i2], 0xa000\n\ts_nop 3\n\ts_or_b32 m0, %[i3], 0xa000\n\ts_nop 3\n\ts_mov_b32 m0, %[kp]"
+                                     : [kp] "=&s"(keep2) : [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]) : "scc");
+                    if (GHF_BX_FOLD3 == 3)
+                        asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\ts_nop 3\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
+                                     : [kp] "=&s"(keep2) : [i0] "s"(ix[0]));
+                    if (GHF_BX_FOLD3 == 4)
+                        asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\ts_nop 3\n\ts_set_gpr_idx_idx %[i1]\n\ts_nop 3\n\t"
+                                     "s_set_gpr_idx_idx %[i2]\n\ts_nop 3\n\ts_set_gpr_idx_idx %[i3]\n\ts_nop 3\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
+                                     : [kp] "=&s"(keep2) : [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]));
+                    return;
+                }
+#endif
                 int keep;
 #define BX_ROW128(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_pk_add_f32 v[64:65], %[y" #i "], v[64:65]\n\t"
 #define BX_ROW64(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_add_f32 v64, %[y" #i "], v64\n\t"
 #define BX_ROW_OPS [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]), [y0] "v"(y[0]), [y1] "v"(y[1]), [y2] "v"(y[2]), [y3] "v"(y[3])
+                // BX_IDX_WAIT: wait states behind BOTH mode switches.  Measured (round 4, tools/hazard_r4*.sh): without them behind
+                // s_set_gpr_idx_on the first add of a block went wrong a few times per launch at four waves per SIMD (hidden 64,
+                // two workgroups per CU) — see the kernel header, "The indexing mode's switch".
                 if constexpr (D == 128)
-                    asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\tv_pk_add_f32 v[64:65], %[y0], v[64:65]\n\t"
+                    asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\t" BX_IDX_WAIT "v_pk_add_f32 v[64:65], %[y0], v[64:65]\n\t"
                                  BX_ROW128(1) BX_ROW128(2) BX_ROW128(3)
-                                 "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
+                                 "s_set_gpr_idx_off\n\t" BX_IDX_WAIT "s_mov_b32 m0, %[kp]"
                                  : BX_PIN_128(sm), [kp] "=&s"(keep) : BX_ROW_OPS);
                 else
-                    asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\tv_add_f32 v64, %[y0], v64\n\t"
+                    asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\t" BX_IDX_WAIT "v_add_f32 v64, %[y0], v64\n\t"
                                  BX_ROW64(1) BX_ROW64(2) BX_ROW64(3)
-                                 "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
+                                 "s_set_gpr_idx_off\n\t" BX_IDX_WAIT "s_mov_b32 m0, %[kp]"
                                  : BX_PIN_64(sm), [kp] "=&s"(keep) : BX_ROW_OPS);
 #undef BX_ROW128
 #undef BX_ROW64
 #undef BX_ROW_OPS
+                for (int t_ = 0; t_ < GHF_BX_FOLDDELAY; ++t_) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             };
             // (straight-line per iteration: a batch in flight across a branch or the loop's back edge gets copied by the
             // compiler — a phi — before its wait, i.e. read before it has landed)
@@ -776,7 +838,12 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 yv_t ya[FB], yb[FB];
                 issue(ya, g);
                 issue(yb, g + FB);
+#if GHF_BX_FOLDDRAIN
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3])::"memory");
+                add_rows(ya, g, false);
+#else
                 add_rows(ya, g, true);
+#endif
                 add_rows(yb, g + FB, false);
             }
         };
@@ -868,7 +935,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         }
         // DMA instructions per tile and helper wave (constant: dma_tile) — what the counted waits below leave in flight
         constexpr int N_SRC = (skip & 1) ? 0 : RBW * NPL, N_DST = ((skip & 2) || YT) ? 0 : RBW * NPL;
-        int sid[6] = {0, 0, 0, 0, 0, 0};                   // source ids of the NEXT chunk's rows (read at the end of a chunk)
+        int sid[6] = {GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT};   // source ids of the NEXT chunk's rows (read at the end of a chunk)
         if (nchunks > 0 && !(skip & 1)) dma_ids(1, P0_IDS, lane, sid);
         for (int k = 0; k < nchunks; ++k) {
             BX_BAR_ARRIVE(k);
@@ -890,6 +957,9 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             if (!(skip & 1) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], P0_IDS, k + 1, l0, sid);
 #if GHF_BX_DRAIN                                           // diagnostics: no two generations of DMAs in flight
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if GHF_BX_SIDLATE
+            if (!(skip & 1)) dma_ids(k + 1, P0_IDS, l0, sid);
 #endif
             if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, P0_NT, l0, sid);
             if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1], false, l0);

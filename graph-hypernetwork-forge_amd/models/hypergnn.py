@@ -159,14 +159,30 @@ class HyperGNN(nn.Module):
         """Cached graph plan for these inputs (cold: O(E) host work + one device sort).  Inference plans of graphs with
         many relations are CSR plans for the relation-stationary layer (_native.prefer_rs); plans that will record
         gradients keep the destination-block geometry the backward kernels run on."""
+        return self._plan_lookup(edge_index, edge_texts, num_nodes, device, training)[0]
+
+    def _plan_lookup(self, edge_index: torch.Tensor, edge_texts: Sequence[str], num_nodes: int, device: torch.device,
+                     training: bool = False, defer_check: bool = False):
+        """(plan, check): the cached plan, or a fresh one.  A hit on a relation list too long for the key's fingerprint to
+        cover whole (plan.FULL_FINGERPRINT_MAX) is confirmed against the snapshot of the list taken when the plan was built
+        (plan.same_relations: ~4 ms at 10 M entries) — here, before returning, or, with `defer_check`, by the caller:
+        `check` is then a callable () -> bool to run once the forward is enqueued (the host is idle while the GPU works);
+        False means the list was edited in place, the result must be dropped and the lookup repeated (it will miss)."""
         key = PlanCache.key(edge_index, edge_texts, num_nodes, self.hidden_dim, device) + (bool(training),)
         plan = self._plans.get(key)
-        if plan is None:
-            unique, ids = relation_ids(edge_texts)
-            wide = not training and _native.prefer_rs(self.hidden_dim, len(unique))
-            plan = build_plan(edge_index, torch.from_numpy(ids), unique, num_nodes, self.hidden_dim, device, force_generic=wide)
-            self._plans.put(key, plan, edge_index, edge_texts)
-        return plan
+        if plan is not None:
+            check = self._plans.verifier(key, edge_texts)
+            if check is None:
+                return plan, None
+            if defer_check:
+                return plan, check
+            if check():
+                return plan, None
+        unique, ids = relation_ids(edge_texts)
+        wide = not training and _native.prefer_rs(self.hidden_dim, len(unique))
+        plan = build_plan(edge_index, torch.from_numpy(ids), unique, num_nodes, self.hidden_dim, device, force_generic=wide)
+        self._plans.put(key, plan, edge_index, edge_texts)
+        return plan, None
 
     def graphed(self, node_features: torch.Tensor, edge_index: torch.Tensor, edge_texts: List[str]) -> GraphedForward:
         """Capture ``forward`` for these inputs into a HIP graph (inference only); see GraphedForward."""
@@ -217,10 +233,20 @@ class HyperGNN(nn.Module):
             raise ValueError(f"node_features must be [N, {self.node_feat_dim}], got {tuple(node_features.shape)}")
         grad = wants_grad(self, node_features) or self._dropping()
         device = node_features.device
-        plan = self.plan_for(edge_index, edge_texts, node_features.size(0), device, training=grad)
+        # The reference maps the strings to ids on every call (:264-268).  Here a cached plan is used at once and, when the
+        # list is too long for the cache key to cover, checked entry by entry on the host WHILE the GPU runs the forward
+        # (forward_planned calls `check` once everything is enqueued); a list edited in place fails the check: fresh plan,
+        # forward again.
+        plan, check = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=grad,
+                                        defer_check=not grad)
         if grad:
             return self._forward_recorded(node_features, plan, edge_index)
-        return self.forward_planned(node_features, plan)
+        stale = []
+        out = self.forward_planned(node_features, plan, host_work=None if check is None else (lambda: stale.append(not check())))
+        if stale and stale[0]:
+            plan, _ = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=False)
+            out = self.forward_planned(node_features, plan)
+        return out
 
     # -- range guard of the two-fp16-piece kernels (include/ghf.h: ghf_set_range_flag) ---------------------------
     def _guarded(self, plan: GraphPlan) -> bool:
@@ -362,7 +388,7 @@ class HyperGNN(nn.Module):
         return weights, ready
 
     def forward_planned(self, node_features: torch.Tensor, plan: GraphPlan,
-                        exchange=None, guard: bool = True) -> torch.Tensor:
+                        exchange=None, guard: bool = True, host_work=None) -> torch.Tensor:
         """Forward with an explicit plan.  `exchange(h)` (multi-GPU) runs after every layer to
         make all rows of h visible on this rank; the plan's row range says which rows it computes.
         Range guard: the kernels that cut rows / weights into two fp16 pieces flag inputs whose dynamic range those do not
@@ -382,6 +408,8 @@ class HyperGNN(nn.Module):
             reader = _native.RangeFlagRead(flag)
         early = reader is not None and os.environ.get("GHF_GUARD_EARLY", "1") != "0"           # (0: read at the end, for A/B)
         out = self._forward_planned(x, plan, exchange, before_last=reader.arm if early else None)
+        if host_work is not None:              # everything is enqueued: host work that hides behind the device's (forward())
+            host_work()
         if guard:
             bits = reader.value()
             self.last_range_flags = bits

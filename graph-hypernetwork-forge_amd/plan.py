@@ -8,8 +8,10 @@ at 10 M edges, far more than the whole device forward.
 
 from __future__ import annotations
 
+import ctypes
 import operator
 import os
+import sys
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -350,19 +352,18 @@ def build_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, unique_texts: Li
 
 
 FULL_FINGERPRINT_MAX = 1 << 17     # lists up to this length are fingerprinted whole
-SAMPLED_POSITIONS = 4096            # longer ones at this many seeded-random positions (plus both ends)
-_SAMPLE_IDX: dict = {}
+SAMPLED_POSITIONS = 4096            # longer ones at this many seeded-random positions (plus both ends): an early miss only —
+_SAMPLE_IDX: dict = {}              # a hit on a longer list is then verified entry by entry (same_relations)
 
 
 def _texts_fingerprint(edge_texts: Sequence[str]) -> Tuple:
-    """What the plan cache compares of a relation list besides its identity and length.
+    """What the plan cache's KEY holds of a relation list besides its identity and length.
 
     The reference maps the strings to ids on every call (models/hypergnn.py:264-268), so a list edited in place must not
     hit a stale plan.  Up to FULL_FINGERPRINT_MAX entries the whole content is hashed (strings cache their hashes: ~1 ms
-    at 2^17); a longer list is sampled at SAMPLED_POSITIONS positions drawn once per length from a seeded generator — an
-    in-place edit of a 10 M-entry list is caught with the probability that it touches a sampled position or changes
-    the length (a full pass over 10 M Python objects costs several warm forwards; `GHF_PLAN_CACHE=0` disables the
-    cache for callers who edit large lists in place, `clear_plan_cache()` drops it once)."""
+    at 2^17).  A longer list is sampled at SAMPLED_POSITIONS positions drawn once per length from a seeded generator: that
+    only turns most edits into an immediate miss — a hit is confirmed against a snapshot of the whole list
+    (`PlanCache.verifier`, `same_relations`) before its result is returned."""
     n = len(edge_texts)
     if n == 0:
         return (0,)
@@ -378,6 +379,60 @@ def _texts_fingerprint(edge_texts: Sequence[str]) -> Tuple:
     return (n, hash(pick[1](edge_texts)))
 
 
+# ---- a long relation list against the snapshot taken when its plan was built ------------------------------------------
+# The snapshot is a shallow copy of the list: it keeps every original string object alive, so no address can be reused and
+# "same pointer" means "same (immutable) string".  CPython keeps a list's items as one array of object pointers
+# (PyListObject.ob_item, behind ob_refcnt / ob_type / ob_size; a tuple's items follow its header directly), so two lists hold
+# the same objects exactly when those arrays are bytewise equal: one memcmp, split over a few threads (ctypes releases the
+# GIL) — 80 MB against 80 MB at 10 M edges, a few milliseconds, which the caller spends while the GPU runs the forward.
+_VERIFY_THREADS = 4
+_verify_pool = None
+
+
+def _item_array_address(seq) -> Optional[int]:
+    if sys.implementation.name != "cpython":
+        return None
+    if type(seq) is list:
+        return ctypes.c_void_p.from_address(id(seq) + 3 * ctypes.sizeof(ctypes.c_void_p)).value
+    if type(seq) is tuple:
+        return id(seq) + 3 * ctypes.sizeof(ctypes.c_void_p)
+    return None
+
+
+def same_objects(a: Sequence, b: Sequence) -> bool:
+    """len(a) == len(b) and a[i] is b[i] for every i (lists / tuples under CPython: a memcmp of the item arrays)."""
+    global _verify_pool
+    n = len(a)
+    if n != len(b):
+        return False
+    if n == 0:
+        return True
+    pa, pb = _item_array_address(a), _item_array_address(b)
+    if pa is None or pb is None:
+        return all(map(operator.is_, a, b))
+    word = ctypes.sizeof(ctypes.c_void_p)
+    memcmp = ctypes.CDLL(None).memcmp
+    memcmp.restype, memcmp.argtypes = ctypes.c_int, (ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+    if n < (1 << 20):
+        return memcmp(pa, pb, n * word) == 0
+    if _verify_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _verify_pool = ThreadPoolExecutor(max_workers=_VERIFY_THREADS, thread_name_prefix="ghf-plan-verify")
+    step = -(-n // _VERIFY_THREADS)
+    jobs = [_verify_pool.submit(memcmp, pa + i * word, pb + i * word, (min(i + step, n) - i) * word) for i in range(0, n, step)]
+    return all(j.result() == 0 for j in jobs)
+
+
+def same_relations(edge_texts: Sequence[str], snapshot: Sequence[str]) -> bool:
+    """Does `edge_texts` still spell the relations its plan was built for?  Same objects (the fast path: an unedited list),
+    else equal strings (a list refilled with equal strings maps to the same ids: reference models/hypergnn.py:264-268)."""
+    if same_objects(edge_texts, snapshot):
+        return True
+    if len(edge_texts) != len(snapshot):
+        return False
+    return (edge_texts if type(edge_texts) is list else list(edge_texts)) == (snapshot if type(snapshot) is list else list(snapshot))
+
+
 class PlanCache:
     """Small LRU of GraphPlans keyed on the identity of the inputs.
 
@@ -385,16 +440,22 @@ class PlanCache:
     the edge_texts list object identity and its content fingerprint
     (`_texts_fingerprint`: the whole list up to 2^17 entries, 4096 seeded-random
     positions beyond); N; d.  The cache keeps references to both inputs so their
-    ids cannot be recycled while an entry lives.  Writes through
-    `edge_index.data` bypass the version counter and are not seen.
-    `GHF_PLAN_CACHE=0` makes every lookup a miss.
+    ids cannot be recycled while an entry lives.  A hit on a list longer than
+    2^17 entries is exact too: the entry holds a snapshot (shallow copy) of the
+    list and `verifier(key, edge_texts)` returns the check the caller runs
+    before it trusts the hit — `HyperGNN.forward` runs it on the host while the
+    GPU computes on the cached plan, and reruns on a fresh plan if it fails —
+    so an in-place edit anywhere is followed, as in the reference
+    (models/hypergnn.py:264-268).  Writes through `edge_index.data` bypass the
+    version counter and are not seen.  `GHF_PLAN_CACHE=0` makes every lookup a miss.
     """
 
     def __init__(self, capacity: int = 4) -> None:
         self.capacity = capacity
-        self._entries: "OrderedDict[Tuple, Tuple[GraphPlan, object, object]]" = OrderedDict()
+        self._entries: "OrderedDict[Tuple, Tuple[GraphPlan, object, object, object]]" = OrderedDict()
         self.hits = 0
         self.misses = 0
+        self.stale = 0                 # hits that the whole-list check turned into misses
 
     @staticmethod
     def key(edge_index: torch.Tensor, edge_texts: Sequence[str], N: int, d: int, device: torch.device,
@@ -415,10 +476,36 @@ class PlanCache:
         return ent[0]
 
     def put(self, key: Tuple, plan: GraphPlan, edge_index: torch.Tensor, edge_texts: Sequence[str]) -> None:
-        self._entries[key] = (plan, edge_index, edge_texts)
+        # (a list the key's fingerprint covers whole needs no snapshot; forward_ids hands over (ids tensor, texts): no list)
+        long_list = isinstance(edge_texts, (list, tuple)) and len(edge_texts) > FULL_FINGERPRINT_MAX and \
+            not (len(edge_texts) == 2 and isinstance(edge_texts[0], torch.Tensor))
+        self._entries[key] = (plan, edge_index, edge_texts, list(edge_texts) if long_list else None)
         self._entries.move_to_end(key)
         while len(self._entries) > self.capacity:
             self._entries.popitem(last=False)
+
+    def verifier(self, key: Tuple, edge_texts: Sequence[str]):
+        """None when a hit on `key` needs no further check; else a callable () -> bool: True when the whole list still spells
+        the plan's relations (a list refilled with equal strings becomes the new snapshot); False drops the entry."""
+        ent = self._entries.get(key)
+        if ent is None or ent[3] is None:
+            return None
+
+        def check() -> bool:
+            snap = ent[3]
+            if same_objects(edge_texts, snap):
+                return True
+            if same_relations(edge_texts, snap):
+                if self._entries.get(key) is ent:
+                    self._entries[key] = ent[:3] + (list(edge_texts),)
+                return True
+            if self._entries.get(key) is ent:
+                del self._entries[key]
+            self.hits -= 1
+            self.misses += 1
+            self.stale += 1
+            return False
+        return check
 
     def clear(self) -> None:
         self._entries.clear()

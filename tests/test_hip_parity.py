@@ -1261,6 +1261,39 @@ def test_relations_edited_in_place_follow_the_reference():
     assert not torch.equal(a, b)
 
 
+def test_long_relation_list_edited_at_an_unsampled_position_follows_the_reference():
+    """Beyond 2^17 edges the plan cache's key samples the list; the hit is then confirmed entry by entry on the host while the GPU
+    runs the forward on the cached plan (HyperGNN.forward / plan.same_relations).  An in-place edit at a position the key does
+    not sample must change the result as the reference's per-call id mapping would (hypergnn.py:264-268)."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    cfg = cases.MODELS["small"]
+    params = cfg.params()
+    model = make_model(cfg, params)
+    N, E, R = 4000, 300_000, 9
+    ei_np, rel = synth.make_graph_arrays(N, E, R, seed=41)
+    names = [f"relation_{i:04d}" for i in range(R)]
+    texts = [names[r] for r in rel.tolist()]
+    x_np = synth.normal(41, "x", (N, cfg.node_feat_dim))
+    x, ei = torch.from_numpy(x_np).to(DEV), torch.from_numpy(ei_np).to(DEV)
+    with torch.no_grad():
+        a = model(x, ei, texts)
+        a2 = model(x, ei, texts)
+        assert torch.equal(a, a2) and model._plans.hits >= 1 and model._plans.stale == 0
+        sampled = set(plan_mod._SAMPLE_IDX[E][0])
+        i = next(p for p in range(E // 2, E) if p not in sampled)
+        texts[i] = names[(rel[i] + 1) % R]                                # that edge now carries another relation
+        b = model(x, ei, texts)
+        assert model._plans.stale == 1
+        b2 = model(x, ei, texts)                                          # (the fresh plan is cached and verified in turn)
+    assert torch.equal(b, b2) and not torch.equal(a, b)
+    keep = ei_np[1] == ei_np[1][i]                                        # the edited edge's destination row, against the oracle
+    rows = np.array([ei_np[1][i]])
+    ref = O.forward(params, x_np, ei_np, texts, variant="factorised").numpy()
+    assert_close(b.cpu().numpy()[rows], ref[rows], "the edited edge's destination row")
+    assert_close(b.cpu().numpy(), ref, "after the in-place edit of a 300 k-entry list")
+    assert keep.any()
+
+
 def test_text_encoder_encode_one():
     """reference tests/test_hypergnn.py:44-63: encode_one gives [text_dim], equal strings equal rows, '' and non-ASCII work."""
     cfg = cases.MODELS["small"]

@@ -165,6 +165,46 @@ def test_relation_ids_first_appearance_order():
     assert ids.dtype == np.int64
 
 
+def test_long_relation_lists_are_verified_entry_by_entry():
+    """A hit on a list longer than the key's fingerprint covers is confirmed against the snapshot the entry holds
+    (plan.same_objects: the lists' item arrays compared bytewise; plan.same_relations: equal strings count as the same
+    relations, reference models/hypergnn.py:264-268)."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    n = plan_mod.FULL_FINGERPRINT_MAX + 70_000
+    names = [f"relation_{i:04d}" for i in range(16)]
+    texts = [names[(7 * i) % 16] for i in range(n)]
+    assert plan_mod.same_objects(texts, list(texts)) and plan_mod.same_objects(tuple(texts[:9]), texts[:9])
+    assert plan_mod.same_objects([], []) and not plan_mod.same_objects(texts, texts[:-1])
+    big = [names[i % 16] for i in range(3_000_000)]                        # (the threaded path)
+    other = list(big)
+    assert plan_mod.same_objects(big, other)
+    other[2_999_999] = "x"
+    assert not plan_mod.same_objects(big, other)
+    ei = torch.zeros(2, n, dtype=torch.int64)
+    dev = torch.device("cpu")
+    cache = PlanCache()
+    key = PlanCache.key(ei, texts, 3, 16, dev)
+    cache.put(key, "plan", ei, texts)
+    sampled = set(plan_mod._SAMPLE_IDX[n][0])
+    pos = next(i for i in range(n // 2, n) if i not in sampled)            # an edit the key cannot see
+    check = cache.verifier(key, texts)
+    assert check is not None and check() and cache.get(key) == "plan"
+    old = texts[pos]
+    texts[pos] = "".join(["relation_", old[9:]])                          # an equal string, another object: same relations
+    assert texts[pos] is not old and PlanCache.key(ei, texts, 3, 16, dev) == key
+    assert cache.verifier(key, texts)() and cache.get(key) == "plan"
+    assert cache.verifier(key, texts)()                                   # (the snapshot now holds the new object: fast path)
+    texts[pos] = names[(int(old[9:]) + 1) % 16]                           # another relation at an unsampled position
+    assert PlanCache.key(ei, texts, 3, 16, dev) == key
+    hits = cache.hits
+    assert cache.get(key) == "plan" and not cache.verifier(key, texts)()
+    assert cache.get(key) is None and cache.stale == 1 and cache.hits == hits
+    short = ["a"] * 10                                                     # lists the key covers whole carry no snapshot
+    k2 = PlanCache.key(ei, short, 3, 16, dev)
+    cache.put(k2, "p2", ei, short)
+    assert cache.verifier(k2, short) is None
+
+
 def test_plan_cache_keys():
     ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
     texts = ["a", "b", "a"]
