@@ -24,8 +24,6 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 import re as _re
 if "stamps" in VARIANT:
     FLAGS.append("-DGHF_STAMPS")
-if "bxcheck" in VARIANT:                                # "bxcheck2": the tile checks too (they slow the consumers)
-    FLAGS.append("-DGHF_BX_CHECK=4" if "bxcheck4" in VARIANT else "-DGHF_BX_CHECK=3" if "bxcheck3" in VARIANT else "-DGHF_BX_CHECK=2" if "bxcheck2" in VARIANT else "-DGHF_BX_CHECK=1")   # 3: an LDS canary only                      # message_bx.hip: tiles verified against the rows they should hold
 if VARIANT == "ablate":
     FLAGS.append("-DGHF_ABLATE")
 _b = _re.search(r"baux(\d+)", VARIANT)
@@ -34,7 +32,7 @@ if _b:
 _x = _re.search(r"bxexp(\d+)", VARIANT)
 if _x:
     FLAGS.append("-DGHF_BXEXP=" + _x.group(1))         # compile-time ablations of message_bx.hip (timing only)
-for _k in ("NPW", "CR", "AD", "ILV", "PRE", "YT", "PRIO", "LATE", "DEFER", "SCHED", "FLAGWAIT", "TGB", "TLOADS", "TCOL", "NT", "PLANLATE", "NOSLEEP", "SWAP1", "PAUSE16", "PAUSE0", "FOLD2", "FOLD3", "FOLDDRAIN", "FOLDDELAY", "SIDINIT", "SIDLATE", "IDXWAIT", "REV", "ASMWAIT", "DRAIN"):               # message_bx.hip geometry: e.g. GHF_VARIANT=bxNPW80_bxCR64
+for _k in ("NPW", "CR", "LATE", "DEFER", "IDXWAIT"):               # message_bx.hip geometry / protocol: e.g. GHF_VARIANT=bxNPW80_bxCR64
     _g = _re.search(r"bx%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX_%s=%s" % (_k, _g.group(1)))

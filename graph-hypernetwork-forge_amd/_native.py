@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 GHF_FLAG_ZERO_SRC = 4

@@ -123,6 +123,10 @@ def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, fl
 
 
 def _raw_message(x: torch.Tensor, plan: GraphPlan, W, W_self, zero_bias: torch.Tensor, zero_half: int, x_split=None, residual=None) -> torch.Tensor:
+    # GHF_FLAG_ZERO_*: "this half must not be read" (include/ghf.h) — the block kernels honour it; the others are handed
+    # packs whose other half really is zero (MessageLayerFn.backward) and no flag
+    if not _native.side_output_supported(plan, x.size(1)):
+        zero_half = 0
     return _message(x, plan, W, W_self, zero_bias, _native.GHF_FLAG_RAW_SUM | zero_half, x_split, residual)
 
 

@@ -182,6 +182,9 @@ int ghf_message_layer_fwd(const float* h, const void* h_split, int64_t N, int d,
     GHF_REQUIRE(!(flags & GHF_FLAG_ADD_H) || (flags & (GHF_FLAG_NO_TAIL | GHF_FLAG_RAW_SUM)), "message_layer_fwd: GHF_FLAG_ADD_H goes with NO_TAIL / RAW_SUM");
     if ((flags & GHF_FLAG_ADD_H) && !ghf_message_side_output_supported(d, block_nodes, wlayout))
         return set_err(GHF_EUNSUPPORTED, "message_layer_fwd: GHF_FLAG_ADD_H is not implemented by the kernel for d=%d, block_nodes=%d, layout %d", d, block_nodes, wlayout);
+    if ((flags & (GHF_FLAG_ZERO_SRC | GHF_FLAG_ZERO_DST)) && !ghf_message_side_output_supported(d, block_nodes, wlayout))
+        return set_err(GHF_EUNSUPPORTED, "message_layer_fwd: GHF_FLAG_ZERO_SRC / ZERO_DST (a half of the weights that must not be read) is "
+                       "not implemented by the kernel for d=%d, block_nodes=%d, layout %d: pack that half as zeros instead", d, block_nodes, wlayout);
     if (agg_out && !ghf_message_side_output_supported(d, block_nodes, wlayout))
         return set_err(GHF_EUNSUPPORTED, "message_layer_fwd: no side output from the kernel for d=%d, block_nodes=%d, layout %d", d, block_nodes, wlayout);
     if (block_nodes == 1) return launch_message_generic(a, (hipStream_t)stream);

@@ -35,6 +35,21 @@
 //              of P1[(k-1)&1]; once all four have folded (flag words), DMA that tile <- destination rows of chunk k+1 (L2; may
 //              land after the barrier); the descriptor pipeline (chunk_tab entry k+5, edge words k+4, row
 //              scales k+3, publish k+2); counted vmcnt wait: the source rows of chunk k+1 are in
+// The indexing mode's switch (round 4: the cause of round 3's "unexplained hazard").  s_set_gpr_idx_on writes MODE.gpr_idx_en; a
+// VALU instruction issued in the very next slot is not guaranteed to see it — the same class as the ISA's "s_setreg of MODE ->
+// vector instruction" rule, which the assembler's and hipcc's hazard handling do not apply to this instruction.  With one helper
+// wave per SIMD (hidden 128, one workgroup per CU) it never showed; at four waves per SIMD (hidden 64, two workgroups per CU) the
+// first indexed add of a four-row block went wrong a few times per launch whenever the schedule put the helpers last at the
+// chunk barrier (round 3's b64DEFER1: 40 of 40 launches, bxLATE0: 300 of 300) and the damage was not confined to the sums: whole
+// 8-row DMA pieces were then gathered with a zeroed id register — from row 0 of h (tools/diag_rows.py).  Located by a
+// single-pad bisect inside the asm block (profiles/r04_hazard_bisect.txt): wait states behind s_set_gpr_idx_on alone make both
+// builds clean, wait states anywhere else do not; a fold without the mode (a select chain over the 48 sums) is clean too; M0
+// traffic and mode switches without a VALU instruction inside are harmless; one wait state is enough (0 of 60), BX_IDX_WAIT
+// puts four behind s_set_gpr_idx_on and four behind s_set_gpr_idx_off (M0's low byte is the index: a VALU instruction that still
+// saw the mode after the restore would be displaced by the low byte of an LDS address).  The instruction pair alone, at 16 waves
+// per CU without MFMA / LDS-DMA neighbours, does not reproduce it (tools/micro/gpr_idx_on_hazard.hip): the rule is kept on the
+// strength of the in-kernel bisect.  RULE: never let the first VALU instruction of an indexing-mode block follow
+// s_set_gpr_idx_on directly, nor a VALU instruction that must not be indexed follow s_set_gpr_idx_off directly.
 // Template parameter SKIP: the instances for the backward's two gradient passes, whose weights have one zero half
 // (GHF_FLAG_ZERO_SRC / GHF_FLAG_ZERO_DST): that half's gathers and products are compiled out.
 #include "common.h"
@@ -101,17 +116,11 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #ifndef GHF_BX_NPW
 #define GHF_BX_NPW 96        // nodes per helper wave at d = 128 (BN = 4 NPW; two registers per node and lane)
 #endif
-// Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results): 1 no B refills, 2 no A-tile DMA, 4 no MFMAs,
-// 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table), 128 one
-// relation's weights for every chunk
+// Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results; tools/pmc_attr.sh): 1 no B refills, 2 no A-tile
+// DMA, 4 no MFMAs, 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table),
+// 128 one relation's weights for every chunk
 #ifndef GHF_BXEXP
 #define GHF_BXEXP 0
-#endif
-#ifndef GHF_BX_AD
-#define GHF_BX_AD 2          // consumers: A-fragment positions read ahead (2, 4, 6 measured the same)
-#endif
-#ifndef GHF_BX_YT
-#define GHF_BX_YT 0
 #endif
 #ifndef GHF_BX_LATE
 #define GHF_BX_LATE 1         // 1: the destination-row tile of chunk k+1 may land after the barrier, behind a flag the consumers
@@ -122,55 +131,20 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #define GHF_BX_DEFER 1        // 1: a chunk's rows are staged AFTER the next barrier (see the consumers' loop): no hand-shake among the
                               // consumers, 3.25 -> 3.13 ms at C3 together with GHF_BX_LATE and the helpers' batched descriptor reads
 #endif
-#ifndef GHF_BX_SCHED
-#define GHF_BX_SCHED 1        // 1: the weight refills of a k-step stay behind its MFMAs (scheduling barriers)
+#ifndef GHF_BX_CR
+#define GHF_BX_CR 76         // rows per chunk
 #endif
-#ifndef GHF_BX_FLAGWAIT
-#define GHF_BX_FLAGWAIT 1      // 1: the staged rows are drained (lgkmcnt) before their flag is set (0 measured the same; kept conservative)
+#ifndef GHF_BX64_NPW
+#define GHF_BX64_NPW 48      // hidden 64: nodes per helper wave (one register per node and lane): blocks of 192 nodes
 #endif
-#ifndef GHF_BX_ILV
-#define GHF_BX_ILV 0          // 1: the previous chunk's rows are staged BETWEEN the k-steps of this chunk's first phase (a slice of the
-                              // ds_write per k-step, behind that k-step's MFMAs) instead of in front of them.  Measured slower
-                              // (same box: 3.18 vs 2.95-3.02 ms per C3 launch): the accumulators live through the phase (5 spilled
-                              // registers reloaded in the loop) and the helpers get the rows ~2,000 cycles later
+#ifndef GHF_BX64_CR
+#define GHF_BX64_CR 64       // hidden 64: rows per chunk (see BxCfg<64>)
 #endif
-#ifndef GHF_BX_PRE
-#define GHF_BX_PRE 1          // bit 0 / bit 1 (first / second phase): a stage's first A fragments are requested AHEAD of the stage — the first phase's behind the barrier,
-                              // in front of the deferred staging writes; the second phase's in front of the first phase's unscale —
-                              // so that their LDS round trip (~370 cycles per stage: tools/stamps_bx.py, "stage prologue") is covered
-#endif
-#ifndef GHF_BX_SWAP1
-#define GHF_BX_SWAP1 1        // 0 (A/B): ZERO_SRC as a second phase without a first one, as in round 2
-#endif
-#ifndef GHF_BX_DRAIN
-#define GHF_BX_DRAIN 0        // diagnostics
-#endif
-#ifndef GHF_BX_ASMWAIT
-#define GHF_BX_ASMWAIT 0      // diagnostics (see wait_flags)
-#endif
-#ifndef GHF_BX_FOLD2
-#define GHF_BX_FOLD2 0        // diagnostics (see fold_plan)
-#endif
-#ifndef GHF_BX_PLANLATE
-#define GHF_BX_PLANLATE 0     // diagnostics
-#endif
-#ifndef GHF_BX_FOLD3
-#define GHF_BX_FOLD3 0        // diagnostics (hidden 64): the fold without the VGPR indexing mode — a select chain over the sums
-#endif
-#ifndef GHF_BX_FOLDDRAIN
-#define GHF_BX_FOLDDRAIN 0    // diagnostics: every row read of a fold step has landed before the indexing mode goes on
-#endif
-#ifndef GHF_BX_FOLDDELAY
-#define GHF_BX_FOLDDELAY 0    // diagnostics: 64-cycle pauses behind every four folded rows (the select-chain fold's pace)
-#endif
-#ifndef GHF_BX_SIDINIT
-#define GHF_BX_SIDINIT 0      // diagnostics: what the source-id registers hold before their first read
-#endif
-#ifndef GHF_BX_SIDLATE
-#define GHF_BX_SIDLATE 0      // diagnostics: the next chunk's source ids read behind the barrier, right before their DMA
+#ifndef GHF_BX64_DEFER
+#define GHF_BX64_DEFER 0     // hidden 64: GHF_BX_DEFER's choice for this size (measured slower there: 0.168 vs 0.164 ms per C2 launch)
 #endif
 #ifndef GHF_BX_IDXWAIT
-#define GHF_BX_IDXWAIT 16     // wait states behind s_set_gpr_idx_on / _off in the fold (0, 1, 2, 4, 8, 16: see add_rows)
+#define GHF_BX_IDXWAIT 4     // wait states behind s_set_gpr_idx_on / _off in the fold (header: "The indexing mode's switch"); 0 = round 3
 #endif
 #if GHF_BX_IDXWAIT == 0
 #define BX_IDX_WAIT ""
@@ -185,45 +159,10 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 #else
 #define BX_IDX_WAIT "s_nop 7\n\ts_nop 7\n\t"
 #endif
-#ifndef GHF_BX_REV
-#define GHF_BX_REV 0          // diagnostics: a tile's DMA pieces issued last piece first
-#endif
-#ifndef GHF_BX_NOSLEEP
-#define GHF_BX_NOSLEEP 0      // diagnostics
-#endif
-#ifndef GHF_BX_PAUSE16
-#define GHF_BX_PAUSE16 1      // what a failed poll of the consumers' staging flags does (see wait_flags)
-#endif
-#ifndef GHF_BX_PAUSE0
-#define GHF_BX_PAUSE0 1       // ... of the helpers' fold flags
-#endif
-#ifndef GHF_BX_NT
-#define GHF_BX_NT 1           // 1: the source-row gathers are non-temporal loads (each row is read once per block and relation)
-#endif
-#ifndef GHF_BX_PRIO
-#define GHF_BX_PRIO 0
-#endif
-#ifndef GHF_BX_CR
-#define GHF_BX_CR 76         // rows per chunk
-#endif
-#ifndef GHF_BX_TLOADS
-#define GHF_BX_TLOADS 1      // 1: the tail's loads of a batch all issued before their first use (see tail_half); measured the same as 0
-#endif
-#ifndef GHF_BX_TCOL
-#define GHF_BX_TCOL 1        // 1: the tail's lanes take columns 4l + 64i (see tail_half): 3.16 -> 3.13 ms; the training forward's launch (one more store) -0.15 ms
-#endif
-#ifndef GHF_BX_TGB
-#define GHF_BX_TGB 3         // tail: four-row groups in flight per wave (six per half at d = 128); measured 1: 3.21, 2: 3.23, 3: 3.18, 4: 3.27 ms
-#endif
-#ifndef GHF_BX64_NPW
-#define GHF_BX64_NPW 48      // hidden 64: nodes per helper wave (one register per node and lane): blocks of 192 nodes
-#endif
-#ifndef GHF_BX64_CR
-#define GHF_BX64_CR 64       // hidden 64: rows per chunk (see BxCfg<64>)
-#endif
-#ifndef GHF_BX64_DEFER
-#define GHF_BX64_DEFER 0     // hidden 64: GHF_BX_DEFER's choice for this size (see BxCfg<64>: 1 is NOT reproducible at two workgroups per CU)
-#endif
+// measured and fixed (round 2-3 A/B records in DESIGN_HISTORY.md): A fragments two positions ahead; weight refills behind their
+// k-step's MFMAs (scheduling barriers); staged rows drained before their flag; the first phase's first fragments requested
+// behind the barrier; non-temporal source gathers; ZERO_SRC as a first phase; the tail's batches of three four-row groups
+constexpr int GHF_BX_AD = 2, GHF_BX_TGB = 3;
 
 // Diagnostic build only (-DGHF_STAMPS): per-wave s_memtime totals per segment.
 // consumers: 0 barrier wait, 1 phase-0 stage, 2 phase-1 stage, 3 staging writes
@@ -251,70 +190,13 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
 #define BX_STAMP_FLUSH()
 #endif
 
-#ifdef GHF_BX_CHECK
-// Diagnostic build (-DGHF_BX_CHECK): consumer wave 0 compares the A tiles in LDS with the rows they should hold (granule slot 0
-// of every live row, both planes) before and after each phase; mismatches go here: [0] = count, then 8 ints per record.
-__device__ int ghf_bx_check_buf[8 + 8 * 8192];
-#endif
-// GHF_BX_CHECK == 4: every flag wait gives up after 2^20 polls, records (block, wave, site, chunk, the four flag words) — code 14 —
-// and goes on (the launch then ends, with wrong results, instead of hanging)
-#if defined(GHF_BX_CHECK) && GHF_BX_CHECK == 4
-#define BX_SPIN_DECL int _spins = 0
-#define BX_SPIN_GIVE_UP(site, kk, f)                                                                        \
-    if (++_spins > (1 << 20)) {                                                                             \
-        if (lane == 0) {                                                                                    \
-            const int _s = atomicAdd(&ghf_bx_check_buf[0], 1);                                              \
-            if (_s < 8192) {                                                                                \
-                int* _o = ghf_bx_check_buf + 8 + 8 * _s;                                                    \
-                _o[0] = (int)blk; _o[1] = (kk); _o[2] = w; _o[3] = 14 * 16 + (site); _o[4] = f[0]; _o[5] = f[1]; _o[6] = f[2]; _o[7] = f[3]; \
-            }                                                                                               \
-        }                                                                                                   \
-        break;                                                                                              \
-    }
-#else
-#define BX_SPIN_DECL
-#define BX_SPIN_GIVE_UP(site, kk, f)
-#endif
-#if defined(GHF_BX_CHECK) && GHF_BX_CHECK < 3
-// the chunk barrier itself: every wave writes the chunk it is about to wait for into its word of the scratch KiB (DUMMY_OFF:
-// unused where RBN % 4 == 0) and, past the barrier, expects all eight words to have reached that chunk (records: code 12)
-#define BX_BAR_ARRIVE(kk)                                                                                   \
-    do {                                                                                                    \
-        if (lane == 0) lds_st_b32(lds0 + DUMMY_OFF + 4 * w, (kk) + 1);                                      \
-        BX_LGKM0();                                                                                         \
-    } while (0)
-#define BX_BAR_INIT()                                                                                       \
-    do {                                                                                                    \
-        if (lane == 0) lds_st_b32(lds0 + DUMMY_OFF + 4 * w, 0);                                             \
-        BX_LGKM0();                                                                                         \
-    } while (0)
-#define BX_BAR_VERIFY(kk)                                                                                   \
-    do {                                                                                                    \
-        int _m = (kk) + 1, _who = -1;                                                                       \
-        for (int _i = 0; _i < 8; ++_i) {                                                                    \
-            const int _a = *(const volatile int*)(smem + DUMMY_OFF + 4 * _i);                               \
-            if (_a < _m) { _m = _a; _who = _i; }                                                            \
-        }                                                                                                   \
-        if (_who >= 0 && lane == 0) {                                                                       \
-            const int _s = atomicAdd(&ghf_bx_check_buf[0], 1);                                              \
-            if (_s < 8192) {                                                                                \
-                int* _o = ghf_bx_check_buf + 8 + 8 * _s;                                                    \
-                _o[0] = (int)blk; _o[1] = (kk); _o[2] = w; _o[3] = 12 * 16; _o[4] = _who; _o[5] = _m; _o[6] = nchunks; _o[7] = 0; \
-            }                                                                                               \
-        }                                                                                                   \
-    } while (0)
-#else
-#define BX_BAR_ARRIVE(kk)
-#define BX_BAR_VERIFY(kk)
-#define BX_BAR_INIT()
-#endif
 
 template <int D> struct BxCfg;
 template <> struct BxCfg<128> {
     static constexpr int NPW = GHF_BX_NPW, CR = GHF_BX_CR;
     static constexpr int BN = 4 * NPW;             // four helper waves
     static constexpr int MTC = (CR + 15) / 16;     // row tiles per chunk
-    static constexpr bool YT = GHF_BX_YT != 0;     // a tile of its own for the staged rows (five tiles in LDS)
+    static constexpr bool YT = false;               // (a fifth tile for the staged rows was measured and dropped: round 2)
     static constexpr size_t LDS = (size_t)(YT ? 5 : 4) * 2 * CR * 256 + 4 * (4 * 16 * MTC + 4) * 4 + 1024 + 512 + 64;
 };
 // hidden 64: a chunk is [rows, 128] x [128, 64] — a quarter of the matrix work per row, so the fixed cost per chunk (~7,000
@@ -322,9 +204,8 @@ template <> struct BxCfg<128> {
 // behind each other: 71 KB of LDS and <= 128 registers per workgroup.  Blocks of 192 nodes: at C2's 32 relations a block and
 // relation hold ~60 rows — one chunk of <= 64 rows, not a full one and a remainder — and C2's 100 k nodes make 521 workgroups
 // for the 512 slots.  Round 3: 0.220 -> 0.155 ms per C2 launch against 256-node blocks, 112-row chunks, one workgroup per CU.
-// GHF_BX64_DEFER = 0 here: with the deferred staging this geometry at two workgroups per CU was NOT bitwise reproducible
-// (a few 8-row fold steps per launch of 170 k went wrong; tools/diag_repro*.py, tools/diag_check.py; the tiles and the ids
-// verified clean in-kernel, GHF_BX_CHECK) — see DESIGN.md, "an unexplained hazard".  Without it: 0 of 300 launches differ.
+// GHF_BX64_DEFER = 0 here: the deferred staging is slower at this size (0.168 vs 0.164 ms per C2 launch, same box).  (Round 3
+// shipped without it because that build was not bitwise reproducible: the indexing mode's switch — see the header.)
 template <> struct BxCfg<64> {
     static constexpr int NPW = GHF_BX64_NPW, CR = GHF_BX64_CR;
     static constexpr int BN = 4 * NPW;
@@ -369,11 +250,11 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
     // its gathers were issued behind the fold and waited for at the next chunk's start (2.41 -> 2.34 ms per C3 launch, same box,
     // GHF_VARIANT=bxSWAP10 for the old form; the 4.8 ms of round 2's training profile was this launch beside the weight
     // gradients' kernel on a second stream)
-    constexpr bool SWAP1 = SKIP == 1 && GHF_BX_SWAP1;
+    constexpr bool SWAP1 = SKIP == 1;
     constexpr int skip = SWAP1 ? 2 : SKIP;
     constexpr int P0_IDS = SWAP1 ? 3 : 2;          // which ids the P0 tiles' rows follow (2: source, 3: destination)
     constexpr int P0_HALF = SWAP1 ? 1 : 0;         // the half of the weights (and the row scales) of the P0 phase
-    constexpr bool P0_NT = GHF_BX_NT != 0 && !SWAP1;   // (a destination row is gathered once per in-edge: default cache policy)
+    constexpr bool P0_NT = !SWAP1;   // (a destination row is gathered once per in-edge: default cache policy)
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, NPW = C::NPW;
     constexpr bool DEFER = D == 64 ? (GHF_BX64_DEFER != 0) : (GHF_BX_DEFER != 0);
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
@@ -454,16 +335,11 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
     auto tail_half = [&](int half, auto gb_c) __attribute__((always_inline)) {          // gb_c: four-row groups in flight per wave
         if (GHF_BXEXP & 32) return;
         const float* acc_lds = (const float*)smem;       // dump rows, natural column order
-#if GHF_BX_TCOL
         // a lane's CPL columns: 4 (lane mod 16) + 64 i + (0..3), i < NV — every 16-byte load / store of a row's 16 lanes is one
         // contiguous 256 bytes (whole 128-byte lines per instruction); adjacent columns per lane left half of each line to the
         // lane's next instruction
         constexpr int CS = 64;
         const int sub = lane >> 4, c0 = 4 * (lane & 15);
-#else
-        constexpr int CS = 4;
-        const int sub = lane >> 4, c0 = CPL * (lane & 15);
-#endif
         constexpr int NV = CPL / 4;                      // 16-byte pieces per lane and row
         auto node_of = [&](int v) -> int { return (v / HPW) * NPW + half * HPW + (v % HPW); };   // block-local node of dump row v
         auto row_sum = [&](float v) -> float {           // over the 16 lanes of a row, result in each of them
@@ -516,9 +392,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 for (int i = 0; i < NV; ++i)              // (GHF_FLAG_ADD_H: the residual operand also without the tail)
                     x[gb][i] = (no_tail && !(no_tail & GHF_FLAG_ADD_H)) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(hp + CS * i);
             }
-#if GHF_BX_TLOADS
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) inv[gb] = (no_tail & GHF_FLAG_RAW_SUM) ? 1.0f : 1.0f / (float)(deg[gb] > 1 ? deg[gb] : 1);
 #pragma unroll
@@ -655,7 +529,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             if (GHF_BXEXP & 2) return;
 #pragma unroll
             for (int i_ = 0; i_ < RBW; ++i_) {
-                const int i = GHF_BX_REV ? RBW - 1 - i_ : i_;
+                const int i = i_;
                 const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
                 // (a piece without live rows is issued too when GHF_BX_LATE: every lane past the buffer — zeros, no memory
                 // access — so that the number of DMA instructions per tile is a constant the counted waits can name)
@@ -673,33 +547,9 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 }
             }
         };
-#if defined(GHF_BX_CHECK) && GHF_BX_CHECK < 3
-        // the ids a DMA is about to use, against the edge arrays (records: code 8 + which)
-        auto check_ids = [&](const BxChunk& c, int which, int kk, int lane, const int (&id)[6]) {
-#pragma unroll
-            for (int i = 0; i < RBW; ++i) {
-                const int rb = hw + TW * i, row = RPP * rb + lane / LPR;
-                if (row < c.rows && (lane & (LPR - 1)) == 0) {
-                    const int want = which == 2 ? (sorted_src[c.e0 + row] & SRC_MASK)
-                                                : (int)((uint32_t)node0 + (sorted_key[c.e0 + row] - (seg0 + (uint32_t)c.r) * (uint32_t)BN));
-                    if (id[i] != want) {
-                        const int slot_i = atomicAdd(&ghf_bx_check_buf[0], 1);
-                        if (slot_i < 8192) {
-                            int* o = ghf_bx_check_buf + 8 + 8 * slot_i;
-                            o[0] = (int)blk; o[1] = kk; o[2] = row; o[3] = (8 + which) * 16 + which * 4; o[4] = id[i]; o[5] = want; o[6] = hw; o[7] = c.rows;
-                        }
-                    }
-                }
-            }
-        };
-#define BX_CHECK_IDS(c, which, kk, lane, id) check_ids(c, which, kk, lane, id)
-#else
-#define BX_CHECK_IDS(c, which, kk, lane, id)
-#endif
         auto dma_tile = [&](unsigned tile_off, int j, int which, const BxChunk& c, bool nt, int lane) {
             int id[6];
             dma_ids(j, which, lane, id);
-            BX_CHECK_IDS(c, which, j, lane, id);
             dma_issue(tile_off, c.rows, nt, lane, id);
         };
         // ---- fold chunk j's staged rows into the registers, row by row -------------------------------------------
@@ -710,27 +560,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         // destination and second source of the adds relative to it (mode 0xa), base register v64.  M0 also holds the LDS
         // base of the wave's LDS-DMA instructions: saved and restored around the mode.  Steps past cnt read the row of
         // zeros into node 0 (no branch inside a step).
-#if GHF_BX_FOLD2
-        // (diagnostics: the one-readlane fold of DESIGN.md's hazard record — m0 / m1: lane j holds the sum-register index of MY
-        //  row number j / 64 + j, 0 behind my last row)
-        struct FoldPlan { int n0, n1, ra, cnt; };
-        auto fold_plan = [&](int j, int rows, int lane) __attribute__((always_inline)) -> FoldPlan {
-            const unsigned dd = lds0 + meta_off(j) + 4 * (3 * CRP);
-            int d0, d1;
-            lds_ld_b32_x2(dd + 4 * lane, dd + 4 * (lane + 64 < CRP ? lane + 64 : CRP - 1), d0, d1);
-            const int base = (int)node0 + hw * NPW;
-            const int n0 = d0 - base, n1 = d1 - base;
-            const unsigned long long q0 = __ballot(lane < rows && (unsigned)n0 < (unsigned)NPW);
-            const unsigned long long q1 = __ballot(lane + 64 < rows && (unsigned)n1 < (unsigned)NPW);
-            const int cnt = __builtin_popcountll(q0) + __builtin_popcountll(q1);
-            const int ra = q0 ? (int)__builtin_ctzll(q0) : 64 + (q1 ? (int)__builtin_ctzll(q1) : 0);
-            const int src = 4 * ((ra + lane) & 63);
-            const int a = __builtin_amdgcn_ds_bpermute(src, n0), b = CRP > 64 ? __builtin_amdgcn_ds_bpermute(src, n1) : 0;
-            const int m0 = lane < cnt ? PL * (ra + lane < 64 ? a : b) : 0;
-            const int m1 = (CRP > 64 && lane + 64 < cnt) ? PL * b : 0;
-            return FoldPlan{m0, m1, ra, cnt};
-        };
-#else
         struct FoldPlan { int n0, n1, ra, cnt; };
         // which of chunk j's rows are mine (one LDS round trip; taken BEFORE the wait for the staged rows: the descriptor has
         // long been published)
@@ -746,7 +575,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             const int ra = q0 ? (int)__builtin_ctzll(q0) : 64 + (q1 ? (int)__builtin_ctzll(q1) : 0);
             return FoldPlan{n0, n1, ra, cnt};
         };
-#endif
         auto fold_rows = [&](int j, const FoldPlan& fp, int lane) __attribute__((always_inline)) {
             const unsigned Y = lds0 + (YT ? Y_OFF : P1_OFF + (unsigned)(j & 1) * TILE);
             const int ra = fp.ra, cnt = fp.cnt;
@@ -775,41 +603,12 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 if (behind) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
                 int ix[FB];
-#if GHF_BX_FOLD2
-                const int msel = (CRP > 64 && r0 >= 64) ? fp.n1 : fp.n0;
-#pragma unroll
-                for (int i = 0; i < FB; ++i) ix[i] = __builtin_amdgcn_readlane(msel, (r0 + i) & 63);
-#else
 #pragma unroll
                 for (int i = 0; i < FB; ++i) {                           // the row's node: lane (row mod 64) of n0 or n1 (both read: no branch)
                     const int rr = ra + r0 + i;
                     const int a = __builtin_amdgcn_readlane(fp.n0, rr & 63), b = __builtin_amdgcn_readlane(fp.n1, rr & 63);
                     ix[i] = r0 + i < cnt ? PL * (rr < 64 ? a : b) : 0;
                 }
-#endif
-#if GHF_BX_FOLD3
-                if constexpr (D == 64) {                                 // (diagnostics: no indexing mode, no M0 traffic)
-#pragma unroll
-                    for (int i = 0; i < FB; ++i)
-#pragma unroll
-                        for (int n = 0; n < NPW; ++n) sm[n / TUP][n % TUP] += ix[i] == n ? y[i] : 0.f;
-                    // 2: and M0 rewritten as the real fold rewrites it (no mode); 3: and the mode switched on and off (no VALU
-                    // instruction inside); 4: as 3 with the real fold's instruction count between (index changes, no adds)
-                    int keep2;
-                    if (GHF_BX_FOLD3 == 2)
-                        asm volatile("s_mov_b32 %[kp], m0\n\ts_or_b32 m0, %[i0], 0xa000\n\ts_nop 3\n\ts_or_b32 m0, %[i1], 0xa000\n\ts_nop 3\n\t"
-                                     "s_or_b32 m0, %[i2], 0xa000\n\ts_nop 3\n\ts_or_b32 m0, %[i3], 0xa000\n\ts_nop 3\n\ts_mov_b32 m0, %[kp]"
-                                     : [kp] "=&s"(keep2) : [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]) : "scc");
-                    if (GHF_BX_FOLD3 == 3)
-                        asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\ts_nop 3\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
-                                     : [kp] "=&s"(keep2) : [i0] "s"(ix[0]));
-                    if (GHF_BX_FOLD3 == 4)
-                        asm volatile("s_mov_b32 %[kp], m0\n\ts_set_gpr_idx_on %[i0], 0xa\n\ts_nop 3\n\ts_set_gpr_idx_idx %[i1]\n\ts_nop 3\n\t"
-                                     "s_set_gpr_idx_idx %[i2]\n\ts_nop 3\n\ts_set_gpr_idx_idx %[i3]\n\ts_nop 3\n\ts_set_gpr_idx_off\n\ts_mov_b32 m0, %[kp]"
-                                     : [kp] "=&s"(keep2) : [i0] "s"(ix[0]), [i1] "s"(ix[1]), [i2] "s"(ix[2]), [i3] "s"(ix[3]));
-                    return;
-                }
-#endif
                 int keep;
 #define BX_ROW128(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_pk_add_f32 v[64:65], %[y" #i "], v[64:65]\n\t"
 #define BX_ROW64(i) "s_set_gpr_idx_idx %[i" #i "]\n\tv_add_f32 v64, %[y" #i "], v64\n\t"
@@ -830,7 +629,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #undef BX_ROW128
 #undef BX_ROW64
 #undef BX_ROW_OPS
-                for (int t_ = 0; t_ < GHF_BX_FOLDDELAY; ++t_) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             };
             // (straight-line per iteration: a batch in flight across a branch or the loop's back edge gets copied by the
             // compiler — a phi — before its wait, i.e. read before it has landed)
@@ -838,50 +636,20 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 yv_t ya[FB], yb[FB];
                 issue(ya, g);
                 issue(yb, g + FB);
-#if GHF_BX_FOLDDRAIN
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3])::"memory");
-                add_rows(ya, g, false);
-#else
                 add_rows(ya, g, true);
-#endif
                 add_rows(yb, g + FB, false);
             }
         };
         // wait until all four words at `flags` have reached v (the waves of one role run the same program: short waits)
-        // (pause_c: what a failed poll does — 1: s_sleep 1; 0: poll again at once; 2: 64 cycles of s_nop.  GHF_BX_PAUSE16 /
-        //  GHF_BX_PAUSE0 choose it for the two waits of a chunk: diagnostics of DESIGN.md's "unexplained hazard")
-        auto wait_flags = [&](unsigned flags, int v, auto pause_c) {
-            constexpr int PAUSE = decltype(pause_c)::value;
-#if GHF_BX_ASMWAIT
-            // (diagnostics: the whole wait in one asm statement — a compare on SCC, no s_cbranch_vccz)
-            int f0, f1, f2, f3, sres;
-            asm volatile("1:\n\t"
-                         "ds_read_b32 %0, %5\n\tds_read_b32 %1, %5 offset:4\n\tds_read_b32 %2, %5 offset:8\n\tds_read_b32 %3, %5 offset:12\n\t"
-                         "s_waitcnt lgkmcnt(0)\n\t"
-                         "v_min_i32 %0, %0, %1\n\tv_min_i32 %2, %2, %3\n\tv_min_i32 %0, %0, %2\n\t"
-                         "s_nop 1\n\t"
-                         "v_readfirstlane_b32 %4, %0\n\t"
-                         "s_cmp_ge_i32 %4, %6\n\t"
-                         "s_cbranch_scc1 2f\n\t"
-                         "s_sleep 1\n\t"
-                         "s_branch 1b\n\t"
-                         "2:"
-                         : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&s"(sres) : "v"(flags), "s"(v) : "memory", "scc");
-            return;
-#endif
-            BX_SPIN_DECL;
+        auto wait_flags = [&](unsigned flags, int v) {
             for (;;) {
                 i32x4 f;
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(flags) : "memory");
                 const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                 if (__builtin_amdgcn_readfirstlane(lo) >= v) break;
-                BX_SPIN_GIVE_UP((int)((flags - lds0 - FLAG_OFF) >> 4), v, f);
-                if constexpr (PAUSE == 1) __builtin_amdgcn_s_sleep(1);
-                if constexpr (PAUSE == 2) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+                __builtin_amdgcn_s_sleep(1);
             }
         };
-        using pause16_t = std::integral_constant<int, GHF_BX_NOSLEEP ? 0 : GHF_BX_PAUSE16>;
-        using pause0_t = std::integral_constant<int, GHF_BX_NOSLEEP ? 0 : GHF_BX_PAUSE0>;
 
         // ---- one workgroup barrier per chunk.  During chunk k (between barriers k and k + 1):
         //   consumers: phase 0 from P0[k&1], phase 1 from P1[k&1]; once all four have read that tile, the chunk's rows Y(k)
@@ -900,10 +668,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 if (lane + 64 * i < 128 + 16) lds_st_b32(lds0 + ZERO_OFF + 4 * (lane + 64 * i), 0);
-#if defined(GHF_BX_CHECK) && GHF_BX_CHECK >= 3               // canary: 240 words of the scratch KiB that nothing may touch
-        if (hw == 0)
-            for (int i = lane; i < 240; i += 64) lds_st_b32(lds0 + DUMMY_OFF + 64 + 4 * i, (int)0xC0FFEE00 + i);
-#endif
         int prev_rows = 1;
         if (nchunks > 0) {
             i32x2 dd[5];
@@ -923,7 +687,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             scP = sc[2];
             wdN = wd[3];
         }
-        BX_BAR_INIT();
         BX_LGKM0();
         __builtin_amdgcn_s_barrier();                      // barrier A: descriptors 0 and 1 visible to all helper waves
         // (raw barriers in this role: __syncthreads() drains every LDS-DMA in flight — vmcnt(0) — before it)
@@ -935,12 +698,10 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         }
         // DMA instructions per tile and helper wave (constant: dma_tile) — what the counted waits below leave in flight
         constexpr int N_SRC = (skip & 1) ? 0 : RBW * NPL, N_DST = ((skip & 2) || YT) ? 0 : RBW * NPL;
-        int sid[6] = {GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT, GHF_BX_SIDINIT};   // source ids of the NEXT chunk's rows (read at the end of a chunk)
+        int sid[6] = {0, 0, 0, 0, 0, 0};                     // source ids of the NEXT chunk's rows (read at the end of a chunk)
         if (nchunks > 0 && !(skip & 1)) dma_ids(1, P0_IDS, lane, sid);
         for (int k = 0; k < nchunks; ++k) {
-            BX_BAR_ARRIVE(k);
             __builtin_amdgcn_s_barrier();                  // ---- chunk k
-            BX_BAR_VERIFY(k);
             BX_STAMP(0);
             const int l0 = opaque_lane(lane);
             if (k > 0) {                                   // everything requested during the last chunk has arrived
@@ -954,13 +715,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             }
             if (!(GHF_BXEXP & 64)) publish(k + 2, ch[2], wdP, scP, l0);
             BX_STAMP(4);
-            if (!(skip & 1) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], P0_IDS, k + 1, l0, sid);
-#if GHF_BX_DRAIN                                           // diagnostics: no two generations of DMAs in flight
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#if GHF_BX_SIDLATE
-            if (!(skip & 1)) dma_ids(k + 1, P0_IDS, l0, sid);
-#endif
             if (!(skip & 1)) dma_issue(P0_OFF + ((k + 1) & 1) * TILE, ch[1].rows, P0_NT, l0, sid);
             if (YT && !(skip & 2)) dma_tile(P1_OFF + ((k + 1) & 1) * TILE, k + 1, 3, ch[1], false, l0);
             if (GHF_BX_LATE && N_DST > 0) {
@@ -973,13 +727,8 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             }
             BX_STAMP(1);
             if (k > 0 && !(GHF_BXEXP & 8)) {
-#if GHF_BX_PLANLATE
-                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k, pause16_t{});
                 const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
-#else
-                const FoldPlan fp = fold_plan(k - 1, prev_rows, l0);
-                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k, pause16_t{});   // all four consumer waves have staged Y(k-1)
-#endif
+                if (DEFER) wait_flags(lds0 + FLAG_OFF + 16, k);   // all four consumer waves have staged Y(k-1)
                 BX_STAMP(5);                               // (stamps: the wait for the staged rows)
                 fold_rows(k - 1, fp, l0);
             }
@@ -991,7 +740,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             BX_STAMP(2);
             // without a tile of their own the staged rows sit where the next destination rows go: every helper wave must have
             // folded them first
-            wait_flags(lds0 + FLAG_OFF, k + 1, pause0_t{});
+            wait_flags(lds0 + FLAG_OFF, k + 1);
             BX_STAMP(3);
             const int l1 = opaque_lane(lane);
             // the next requests of the descriptor pipeline: behind the loops above (a load in flight across a loop makes hipcc
@@ -1002,7 +751,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 wdL = load_words(ch[4], l1);
             }
             d5 = load_desc(k + 5);
-            if (!YT && !(skip & 2) && k + 1 < nchunks) BX_CHECK_IDS(ch[1], 3, k + 1, l1, did);
             if (!YT && !(skip & 2)) dma_issue(P1_OFF + ((k + 1) & 1) * TILE, ch[1].rows, false, l1, did);
             BX_STAMP(1);
             prev_rows = ch[0].rows;
@@ -1024,19 +772,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the tiles are reused below
         BX_LGKM0();
         BX_STAMP(5);
-#if defined(GHF_BX_CHECK) && GHF_BX_CHECK >= 3
-        if (hw == 1)
-            for (int i = lane; i < 240; i += 64) {
-                const int got = *(const volatile int*)(smem + DUMMY_OFF + 64 + 4 * i);
-                if (got != (int)0xC0FFEE00 + i) {
-                    const int slot_i = atomicAdd(&ghf_bx_check_buf[0], 1);
-                    if (slot_i < 8192) {
-                        int* o = ghf_bx_check_buf + 8 + 8 * slot_i;
-                        o[0] = (int)blk; o[1] = nchunks; o[2] = i; o[3] = 13 * 16; o[4] = got; o[5] = (int)0xC0FFEE00 + i; o[6] = 0; o[7] = 0;
-                    }
-                }
-            }
-#endif
         if constexpr (D == 128) asm volatile("" : BX_PIN_128(sm)); else asm volatile("" : BX_PIN_64(sm));
         // dump row HPW*hw + i = node NPW*hw + HPW*half + i, natural column order: position PL*lane + e is column
         // 32 (lane / 16) + 16 e + lane % 16 at d = 128 (a consumer wave's two fragments, interleaved), column lane at d = 64
@@ -1067,9 +802,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         BX_STAMP_FLUSH();
     } else {
         // =============================================== CONSUMERS ===============================================
-#if GHF_BX_PRIO
-        __builtin_amdgcn_s_setprio(GHF_BX_PRIO);           // (experiment) the matrix waves ahead of their SIMD's helper wave
-#endif
         // B fragments (GHF_WLAYOUT_SPLIT2H): Wh[r][o/16][kk/32][piece][lane][8] fp16, then one float 2^-s per relation
         const uint32_t wsc_off = (uint32_t)((uint64_t)R * 2 * D * D * (NPL * 2));
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wsplit, 0, (int)wsc_off, 0x00020000);
@@ -1094,7 +826,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
         // function, called through s_swappc with its captures in scratch: 10x the time)
         constexpr int AD = GHF_BX_AD;
         static_assert(AD <= MTC - 2, "the prefetched positions are row tiles 0 .. AD-1 of the first k-step in every instance");
-        i32x4 apre[AD][NPL];                               // GHF_BX_PRE: the fragments of a stage's first AD positions
+        i32x4 apre[AD][NPL];                               // the fragments of a stage's first AD positions, requested ahead of the stage
         auto lda_from = [&](const char* Abuf, int j, int m, i32x4 (&dst)[NPL]) __attribute__((always_inline)) {
             const char* src = Abuf + arow + (((4 * j + q) ^ akey(c16)) << 4) + m * 16 * ROWB;     // akey(16 m + c16) = akey(c16)
 #pragma unroll
@@ -1159,18 +891,14 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                         }
                     }
                 }
-#if GHF_BX_SCHED
                 __builtin_amdgcn_sched_barrier(0);
-#endif
                 BX_STAMP(5);
                 between(j);
                 if (!(GHF_BXEXP & 1)) load_b_step(r_next, ph_next, j);
-#if GHF_BX_SCHED
                 __builtin_amdgcn_sched_barrier(0);
-#endif
                 BX_STAMP(7);
             }
-            after_k();                                      // (GHF_BX_PRE: the next stage's first fragments, requested before the unscale)
+            after_k();                                      // (hook: the next stage's first fragments, requested before the unscale)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -1234,31 +962,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 }
             }
         };
-#ifdef GHF_BX_CHECK
-        auto check_tile = [&](unsigned tile_off, int which, const int* meta, const BxChunk& c, int kk, int code) {
-            if (tw != 0) return;
-            for (int r = lane; r < c.rows; r += 64) {
-                const int id = meta[which * CRP + r];
-                const int want_id = which == 2 ? (sorted_src[c.e0 + r] & SRC_MASK)
-                                               : (int)((uint32_t)node0 + (sorted_key[c.e0 + r] - (seg0 + (uint32_t)c.r) * (uint32_t)BN));
-                for (int pl = 0; pl < NPL; ++pl) {
-                    const i32x4 lv = *(const i32x4*)(smem + tile_off + pl * PLANE + r * ROWB);
-                    const i32x4 gv = *(const i32x4*)((const char*)h_split + (size_t)want_id * HROW + pl * ROWB + (akey(r) << 4));
-                    const bool bad = lv[0] != gv[0] || lv[1] != gv[1] || lv[2] != gv[2] || lv[3] != gv[3] || id != want_id;
-                    if (bad) {
-                        const int slot_i = atomicAdd(&ghf_bx_check_buf[0], 1);
-                        if (slot_i < 8192) {
-                            int* o = ghf_bx_check_buf + 8 + 8 * slot_i;
-                            o[0] = (int)blk; o[1] = kk; o[2] = r; o[3] = code * 16 + which * 4 + pl; o[4] = id; o[5] = want_id; o[6] = lv[0]; o[7] = gv[0];
-                        }
-                    }
-                }
-            }
-        };
-#define BX_CHECK(tile, which, code) do { if (GHF_BX_CHECK == 2) check_tile(tile, which, meta, ch, k, code); } while (0)
-#else
-#define BX_CHECK(tile, which, code)
-#endif
         auto nothing = [](int) {};
         const int ph_first = (skip & 1) ? 1 : P0_HALF;      // the weights' half of a chunk's first live phase
         BxChunk ch{0, 0, 1};
@@ -1278,45 +981,37 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
 #pragma unroll
             for (int j = 0; j < KS; ++j) load_b_step(ch.r, ph_first, j);
         }
-        BX_BAR_INIT();
         __syncthreads();                                   // barrier A
         for (int k = 0; k < nchunks; ++k) {
             const int mt = (ch.rows + 15) >> 4;
             const int* meta = (const int*)(smem + meta_off(k));
-            BX_BAR_ARRIVE(k);
             __syncthreads();                               // ---- chunk k
-            BX_BAR_VERIFY(k);
             BX_STAMP(0);
             constexpr bool PRE_OK = skip == 0 && !YT && GHF_BX_LATE;
-            constexpr bool PRE0 = (GHF_BX_PRE & 1) && PRE_OK, PRE1 = (GHF_BX_PRE & 2) && PRE_OK;      // first / second phase
+            constexpr bool PRE0 = PRE_OK, PRE1 = false;        // first / second phase (the second phase's ahead of the unscale: 44 spilled registers)
             using pre0_t = std::integral_constant<bool, PRE0>;
             using pre1_t = std::integral_constant<bool, PRE1>;
             if (PRE0) prefetch_a(smem + P0_OFF + (k & 1) * TILE);      // (chunk k's source rows landed before the barrier)
             // GHF_BX_DEFER: the previous chunk's rows go to their staging tile (that chunk's destination-row tile) only now:
             // behind the barrier every consumer wave is through with that tile, so there is no hand-shake among the consumers,
             // and the accumulators are not needed before this chunk's first phase ends.  The helpers wait for the flag.
-            constexpr bool ILV = GHF_BX_ILV && DEFER && !(skip & 1) && !(GHF_BXEXP & 16);
+            constexpr bool ILV = false;                         // (staging writes between the k-steps: measured slower, round 3)
             if (DEFER && k > 0 && !ILV) {
                 if (!(GHF_BXEXP & 16)) write_rows(mt_prev, P1_OFF + ((k - 1) & 1) * TILE);
-#if GHF_BX_FLAGWAIT
                 BX_LGKM0();
-#endif
                 if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
                 BX_STAMP(3);
             }
             const BxChunk nx = decode(dn);
-            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, P0_IDS, 0);
             // (a half whose weights the caller declared zero is not computed: the next live stage's weights are prefetched)
             // behind the first phase's k-steps: this chunk's destination rows have landed (helpers' flags) -> the second phase's
             // first fragments are requested before the first phase's unscale
             auto wait_landed = [&]() __attribute__((always_inline)) {
-                BX_SPIN_DECL;
                 for (;;) {
                     i32x4 f;
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + FLAG_OFF + 32) : "memory");
                     const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                     if (__builtin_amdgcn_readfirstlane(lo) >= k + 1) break;
-                    BX_SPIN_GIVE_UP(8 + 2, k + 1, f);
                     __builtin_amdgcn_s_sleep(1);
                 }
             };
@@ -1341,11 +1036,9 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 if (lane == 0) lds_st_b32(lds0 + FLAG_OFF + 16 + 4 * tw, k);
             }
             BX_STAMP(1);
-            if (!(skip & 1)) BX_CHECK(P0_OFF + (k & 1) * TILE, P0_IDS, 1);
             dn = load_desc(k + 2);
             load_rel_words(nx.r, wscale_n, bias_n);
             if (GHF_BX_LATE && !(skip & 2) && !YT && !PRE1) wait_landed();   // the destination-row tile of this chunk has landed (helpers' flags)
-            if (!(skip & 2)) BX_CHECK(P1_OFF + (k & 1) * TILE, 3, 2);
             if (skip & 1) {                                // no source phase ran: the destination phase adds to the bias
 #pragma unroll
                 for (int m = 0; m < MTC; ++m)
@@ -1353,7 +1046,6 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){bias_v[t], bias_v[t], bias_v[t], bias_v[t]};
             }
             if (!(skip & 2)) stage_for(mt, pre1_t{}, 1, false, smem + P1_OFF + (k & 1) * TILE, meta, wscale, nx.r, ph_first, bias_v, nothing, no_after);
-            if (!(skip & 2)) BX_CHECK(P1_OFF + (k & 1) * TILE, 3, 3);
             BX_STAMP(2);
             // YT: the staging tile is free once every helper wave has folded the previous chunk's rows (flag = k + 1, set during
             // this chunk); else the chunk's rows overwrite its destination-row tile once every consumer wave has read it
@@ -1364,13 +1056,11 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 const unsigned fw = DEFER ? FLAG_OFF + 48 : FLAG_OFF + (YT ? 0 : 16);      // (DEFER: words of their own)
                 const int fv = DEFER ? 1 : k + 1;
                 if (!YT && lane == 0) lds_st_b32(lds0 + (DEFER ? FLAG_OFF + 48 : FLAG_OFF + 16) + 4 * tw, fv);
-                BX_SPIN_DECL;
                 for (;;) {
                     i32x4 f;
                     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(lds0 + fw) : "memory");
                     const int lo = min(min(f[0], f[1]), min(f[2], f[3]));
                     if (__builtin_amdgcn_readfirstlane(lo) >= fv) break;
-                    BX_SPIN_GIVE_UP(8 + (int)((fw - FLAG_OFF) >> 4), fv, f);
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!(GHF_BXEXP & 16)) write_rows(mt, YT ? Y_OFF : P1_OFF + (k & 1) * TILE);
@@ -1421,9 +1111,7 @@ static int launch_bx_for(const MsgArgs& a, hipStream_t stream) {
     GHF_REQUIRE(a.n_items >= cdiv(a.rows, C::BN), "message(bx): n_items=%lld is fewer than the blocks of the row range", (long long)a.n_items);
     GHF_REQUIRE(a.n_items == cdiv(a.rows, C::BN) || a.partial, "message(bx): split blocks need the `partial` scratch");
     const int skip = ((a.flags & GHF_FLAG_ZERO_SRC) ? 1 : 0) | ((a.flags & GHF_FLAG_ZERO_DST) ? 2 : 0);
-    // GHF_BX_LDS_PAD=<bytes> (diagnostics): a larger LDS request — e.g. one workgroup per CU where two would fit
-    static const size_t lds_pad = [] { const char* e = getenv("GHF_BX_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    const size_t lds_dyn = lds + lds_pad <= 160 * 1024 ? lds + lds_pad : lds;
+    const size_t lds_dyn = lds;
     auto go = [&](auto skip_c) {
         constexpr int S = decltype(skip_c)::value;
         GHF_SET_MAX_LDS((message_bx_kernel<D, S>), lds_dyn);
@@ -1498,13 +1186,6 @@ int launch_message_bx(const MsgArgs& a, hipStream_t stream) {
 
 }  // namespace ghf
 
-#ifdef GHF_BX_CHECK
-extern "C" int ghf_debug_read_check_bx(int* host, size_t count, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_check_buf), count * sizeof(int));
-    if (reset) { int z = 0; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(ghf::ghf_bx_check_buf), &z, sizeof(int)); }
-    return rc;
-}
-#endif
 #ifdef GHF_STAMPS
 extern "C" int ghf_debug_read_stamps_bx(unsigned long long* host, size_t count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_stamp_buf), count * sizeof(unsigned long long));

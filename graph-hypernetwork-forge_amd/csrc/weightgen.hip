@@ -279,7 +279,6 @@ __global__ __launch_bounds__(1024) void wg_pack2h_kernel(PackL WL, int R, int d,
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
     {   // range guard, weak input rows (common.h: WeakRows): L1 norms of the 2d rows, a wave per row
         WeakRows wr;
-    wr.init();
         wr.init();
         const int lane = tid & 63, wv = tid >> 6;
         for (int row = wv; row < 2 * d; row += 16) {

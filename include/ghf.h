@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 13
+#define GHF_ABI_VERSION 14
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -39,9 +39,12 @@ extern "C" {
 /* ghf_message_layer_fwd flags */
 #define GHF_FLAG_NO_TAIL  1   /* write sum_e(...) / max(indeg,1) only: skip residual+ReLU+LayerNorm */
 #define GHF_FLAG_RAW_SUM  2   /* (implies NO_TAIL) write sum_e(...) itself, no division: the backward passes */
-#define GHF_FLAG_ZERO_SRC 4   /* the caller states that the source half of every relation's weights (W_msg) is zero: a kernel
-                                 may skip the source-row gathers and their products (the two gradient passes of the backward
-                                 each have one zero half); the result is the same with or without the flag */
+#define GHF_FLAG_ZERO_SRC 4   /* the kernel MUST leave the source half of every relation's weights (W_msg) out: no source-row
+                                 gathers, no products with that half — whatever the packed tensor holds there (the backward
+                                 hands ONE packed [W_msg^T; W_self^T] to both of its gradient passes and names the half each
+                                 pass must not read; a half that really is zero gives the same result without the flag).
+                                 Honoured by the kernels with the side output (ghf_message_side_output_supported) only:
+                                 elsewhere the call returns GHF_EUNSUPPORTED — pack that half as zeros and drop the flag */
 #define GHF_FLAG_ZERO_DST 8   /* the same for the destination half (W_self); not both */
 #define GHF_FLAG_ADD_H   16   /* with NO_TAIL / RAW_SUM: h_out = (that result) + h — `h` then only names the rows to add (the gathers use
                                  h_split): the backward accumulates its gradient terms this way.  Kernels with the side
