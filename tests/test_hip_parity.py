@@ -130,8 +130,9 @@ def test_hidden_64_gradient_pass_instances_match_the_oracle_at_half_a_million_ed
     e_src, e_dst, e_rel = ei[0][keep], ei[1][keep], rel[keep]
     h64 = h.astype(np.float64)
     want = np.zeros((N, d))
-    Wm64 = np.zeros_like(Wm, dtype=np.float64) if top is None else Wm.astype(np.float64)
-    Ws64 = np.zeros_like(Ws, dtype=np.float64) if bottom is None else Ws.astype(np.float64)
+    # (packed transposed, as the backward packs them: the passes multiply by W^T)
+    Wm64 = np.zeros_like(Wm, dtype=np.float64) if top is None else Wm.astype(np.float64).transpose(0, 2, 1)
+    Ws64 = np.zeros_like(Ws, dtype=np.float64) if bottom is None else Ws.astype(np.float64).transpose(0, 2, 1)
     for r in range(R):
         m = e_rel == r
         np.add.at(want, e_dst[m], h64[e_src[m]] @ Wm64[r] + h64[e_dst[m]] @ Ws64[r] + b[r].astype(np.float64))
