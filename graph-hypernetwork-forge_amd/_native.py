@@ -38,6 +38,7 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size
 SIGNATURES = {
     "ghf_abi_version": (_i32, []),
     "ghf_last_error": (C.c_char_p, []),
+    "ghf_host_checksum64": (C.c_uint64, [_vp, _sz, C.c_uint64]),
     "ghf_message_config": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ghf_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "ghf_plan_max_chunks": (_i64, [_i64, _i64, _i32, _i32, _i32]),
@@ -140,7 +141,7 @@ class _Traced:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if not name.startswith("ghf_") or name in ("ghf_last_error", "ghf_abi_version"):
+        if not name.startswith("ghf_") or name in ("ghf_last_error", "ghf_abi_version", "ghf_host_checksum64"):
             return fn
 
         def call(*args):

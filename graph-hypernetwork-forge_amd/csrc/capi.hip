@@ -37,6 +37,25 @@ int ghf_set_range_flag(int32_t* device_word) {
 
 int ghf_abi_version(void) { return GHF_ABI_VERSION; }
 
+unsigned long long ghf_host_checksum64(const void* p, size_t nbytes, unsigned long long seed) {
+    // four independent multiply-xor lanes over 32-byte strides (memory-bound from ~2 lanes on), folded with their positions
+    const unsigned long long K0 = 0x9E3779B97F4A7C15ull, K1 = 0xC2B2AE3D27D4EB4Full, K2 = 0x165667B19E3779F9ull, K3 = 0x27D4EB2F165667C5ull;
+    const unsigned long long* w = (const unsigned long long*)p;
+    const size_t n = nbytes / 8;
+    unsigned long long h0 = seed ^ K0, h1 = seed ^ K1, h2 = seed ^ K2, h3 = seed ^ K3;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        h0 = (h0 ^ w[i]) * K1;      h0 ^= h0 >> 29;
+        h1 = (h1 ^ w[i + 1]) * K2;  h1 ^= h1 >> 31;
+        h2 = (h2 ^ w[i + 2]) * K3;  h2 ^= h2 >> 27;
+        h3 = (h3 ^ w[i + 3]) * K0;  h3 ^= h3 >> 33;
+    }
+    for (; i < n; ++i) { h0 = (h0 ^ w[i]) * K1; h0 ^= h0 >> 29; }
+    unsigned long long h = (h0 * K0) ^ (h1 * K1 + 1) ^ (h2 * K2 + 2) ^ (h3 * K3 + 3) ^ (unsigned long long)n;
+    h ^= h >> 32; h *= K2; h ^= h >> 29;
+    return h;
+}
+
 const char* ghf_last_error(void) { return err_buf(); }
 
 int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks) {

@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from .. import _native
 from ..plan import GraphPlan, PlanCache, build_plan, build_rs, exact_plan, relation_ids
+from ..plan import check_pool
 from .weight_generator import WeightGenerator, check_dropout, draw_mask, require_inference, wants_grad
 
 
@@ -234,16 +235,17 @@ class HyperGNN(nn.Module):
         grad = wants_grad(self, node_features) or self._dropping()
         device = node_features.device
         # The reference maps the strings to ids on every call (:264-268).  Here a cached plan is used at once and, when the
-        # list is too long for the cache key to cover, checked entry by entry on the host WHILE the GPU runs the forward
-        # (forward_planned calls `check` once everything is enqueued); a list edited in place fails the check: fresh plan,
-        # forward again.
+        # list is too long for the cache key to cover, checked entry by entry on the host WHILE the GPU runs the forward; a
+        # list edited in place fails the check: fresh plan, forward again.
         plan, check = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=grad,
                                         defer_check=not grad)
         if grad:
             return self._forward_recorded(node_features, plan, edge_index)
-        stale = []
-        out = self.forward_planned(node_features, plan, host_work=None if check is None else (lambda: stale.append(not check())))
-        if stale and stale[0]:
+        # (the check runs on the plan cache's threads, outside the GIL, beside this thread's launches and its wait for the
+        # range-guard word; its result is collected before the output is handed back)
+        pending = None if check is None else check_pool().submit(check)
+        out = self.forward_planned(node_features, plan)
+        if pending is not None and not pending.result():
             plan, _ = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=False)
             out = self.forward_planned(node_features, plan)
         return out
@@ -388,7 +390,7 @@ class HyperGNN(nn.Module):
         return weights, ready
 
     def forward_planned(self, node_features: torch.Tensor, plan: GraphPlan,
-                        exchange=None, guard: bool = True, host_work=None) -> torch.Tensor:
+                        exchange=None, guard: bool = True) -> torch.Tensor:
         """Forward with an explicit plan.  `exchange(h)` (multi-GPU) runs after every layer to
         make all rows of h visible on this rank; the plan's row range says which rows it computes.
         Range guard: the kernels that cut rows / weights into two fp16 pieces flag inputs whose dynamic range those do not
@@ -408,8 +410,6 @@ class HyperGNN(nn.Module):
             reader = _native.RangeFlagRead(flag)
         early = reader is not None and os.environ.get("GHF_GUARD_EARLY", "1") != "0"           # (0: read at the end, for A/B)
         out = self._forward_planned(x, plan, exchange, before_last=reader.arm if early else None)
-        if host_work is not None:              # everything is enqueued: host work that hides behind the device's (forward())
-            host_work()
         if guard:
             bits = reader.value()
             self.last_range_flags = bits

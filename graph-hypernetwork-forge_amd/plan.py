@@ -380,13 +380,36 @@ def _texts_fingerprint(edge_texts: Sequence[str]) -> Tuple:
 
 
 # ---- a long relation list against the snapshot taken when its plan was built ------------------------------------------
-# The snapshot is a shallow copy of the list: it keeps every original string object alive, so no address can be reused and
-# "same pointer" means "same (immutable) string".  CPython keeps a list's items as one array of object pointers
-# (PyListObject.ob_item, behind ob_refcnt / ob_type / ob_size; a tuple's items follow its header directly), so two lists hold
-# the same objects exactly when those arrays are bytewise equal: one memcmp, split over a few threads (ctypes releases the
-# GIL) — 80 MB against 80 MB at 10 M edges, a few milliseconds, which the caller spends while the GPU runs the forward.
-_VERIFY_THREADS = 4
+# The snapshot is a shallow copy of the list — it keeps every original string object alive, so no address can be reused and
+# "same pointer" means "same (immutable) string" — plus checksums of its array of object pointers.  CPython keeps a list's
+# items as one array of pointers (PyListObject.ob_item, behind ob_refcnt / ob_type / ob_size; a tuple's items follow its header
+# directly); a hit is confirmed by checksumming the LIVE list's array (ghf_host_checksum64 over a few threads — ctypes releases
+# the GIL; 80 MB at 10 M edges, ~4 ms, memory-bound) and comparing with the snapshot's: an unedited list never costs more.
+# A mismatch falls back to comparing the strings themselves.
+_VERIFY_THREADS = max(1, min(8, (os.cpu_count() or 4)))
+_VERIFY_MIN_PARALLEL = 1 << 20
 _verify_pool = None
+
+
+def _pool():
+    global _verify_pool
+    if _verify_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _verify_pool = ThreadPoolExecutor(max_workers=_VERIFY_THREADS, thread_name_prefix="ghf-plan-verify")
+    return _verify_pool
+
+
+_check_pool = None
+
+
+def check_pool():
+    """Where HyperGNN.forward runs a cache hit's whole-list check beside its launches (apart from `_pool`, whose workers
+    the check itself waits on)."""
+    global _check_pool
+    if _check_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _check_pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="ghf-plan-check")
+    return _check_pool
 
 
 def _item_array_address(seq) -> Optional[int]:
@@ -399,28 +422,32 @@ def _item_array_address(seq) -> Optional[int]:
     return None
 
 
-def same_objects(a: Sequence, b: Sequence) -> bool:
-    """len(a) == len(b) and a[i] is b[i] for every i (lists / tuples under CPython: a memcmp of the item arrays)."""
-    global _verify_pool
-    n = len(a)
-    if n != len(b):
-        return False
+def pointer_checksums(seq: Sequence) -> Optional[Tuple[int, ...]]:
+    """Checksums of the object pointers `seq` holds (its identity, entry by entry), one per slice of the list; None where the
+    item array cannot be addressed (not CPython, not a list / tuple)."""
+    n = len(seq)
+    base = _item_array_address(seq)
+    if base is None:
+        return None
     if n == 0:
-        return True
-    pa, pb = _item_array_address(a), _item_array_address(b)
-    if pa is None or pb is None:
-        return all(map(operator.is_, a, b))
+        return (0,)
     word = ctypes.sizeof(ctypes.c_void_p)
-    memcmp = ctypes.CDLL(None).memcmp
-    memcmp.restype, memcmp.argtypes = ctypes.c_int, (ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
-    if n < (1 << 20):
-        return memcmp(pa, pb, n * word) == 0
-    if _verify_pool is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _verify_pool = ThreadPoolExecutor(max_workers=_VERIFY_THREADS, thread_name_prefix="ghf-plan-verify")
+    fn = _native.load().ghf_host_checksum64
+    if n < _VERIFY_MIN_PARALLEL:
+        return (n, fn(base, n * word, 0))
     step = -(-n // _VERIFY_THREADS)
-    jobs = [_verify_pool.submit(memcmp, pa + i * word, pb + i * word, (min(i + step, n) - i) * word) for i in range(0, n, step)]
-    return all(j.result() == 0 for j in jobs)
+    jobs = [_pool().submit(fn, base + i * word, (min(i + step, n) - i) * word, i) for i in range(0, n, step)]
+    return (n,) + tuple(j.result() for j in jobs)
+
+
+def same_objects(a: Sequence, b: Sequence) -> bool:
+    """len(a) == len(b) and a[i] is b[i] for every i."""
+    if len(a) != len(b):
+        return False
+    ca, cb = pointer_checksums(a), pointer_checksums(b)
+    if ca is None or cb is None:
+        return all(map(operator.is_, a, b))
+    return ca == cb
 
 
 def same_relations(edge_texts: Sequence[str], snapshot: Sequence[str]) -> bool:
@@ -479,25 +506,33 @@ class PlanCache:
         # (a list the key's fingerprint covers whole needs no snapshot; forward_ids hands over (ids tensor, texts): no list)
         long_list = isinstance(edge_texts, (list, tuple)) and len(edge_texts) > FULL_FINGERPRINT_MAX and \
             not (len(edge_texts) == 2 and isinstance(edge_texts[0], torch.Tensor))
-        self._entries[key] = (plan, edge_index, edge_texts, list(edge_texts) if long_list else None)
+        snap = None
+        if long_list:
+            copy = list(edge_texts)
+            snap = [copy, pointer_checksums(copy)]
+        self._entries[key] = (plan, edge_index, edge_texts, snap)
         self._entries.move_to_end(key)
         while len(self._entries) > self.capacity:
             self._entries.popitem(last=False)
 
     def verifier(self, key: Tuple, edge_texts: Sequence[str]):
-        """None when a hit on `key` needs no further check; else a callable () -> bool: True when the whole list still spells
-        the plan's relations (a list refilled with equal strings becomes the new snapshot); False drops the entry."""
+        """None when a hit on `key` needs no further check; else a callable () -> bool (thread-safe, GIL-free for most of its
+        time): True when the whole list still spells the plan's relations (a list refilled with equal strings becomes the new
+        snapshot); False drops the entry."""
         ent = self._entries.get(key)
         if ent is None or ent[3] is None:
             return None
 
         def check() -> bool:
             snap = ent[3]
-            if same_objects(edge_texts, snap):
+            live = pointer_checksums(edge_texts)
+            if live is not None and live == snap[1]:
                 return True
-            if same_relations(edge_texts, snap):
-                if self._entries.get(key) is ent:
-                    self._entries[key] = ent[:3] + (list(edge_texts),)
+            if live is None and same_objects(edge_texts, snap[0]):
+                return True
+            if same_relations(edge_texts, snap[0]):
+                copy = list(edge_texts)
+                snap[0], snap[1] = copy, pointer_checksums(copy)
                 return True
             if self._entries.get(key) is ent:
                 del self._entries[key]

@@ -61,6 +61,11 @@ extern "C" {
 int         ghf_abi_version(void);
 const char* ghf_last_error(void);
 
+/* HOST function (no device work, no stream): a position-dependent 64-bit checksum of `nbytes` bytes (a multiple of 8) at `p`.
+ * The plan cache confirms a hit on a long relation list with it: the list's array of object pointers against the checksums
+ * taken when the plan was built — the per-call string -> id mapping of models/hypergnn.py:264-268 at memory speed. */
+unsigned long long ghf_host_checksum64(const void* p, size_t nbytes, unsigned long long seed);
+
 /* Which plan geometry and weight layout the message kernel for hidden size d wants.
  * block_nodes == 1 means "CSR by destination" (the generic kernel; chunk_rows == split_chunks == 0 then). */
 int ghf_message_config(int d, int* block_nodes, int* wlayout, int* chunk_rows, int* split_chunks);
