@@ -247,6 +247,7 @@ def main():
 
     runner = None
     exchange_pick = None
+    exchange_why = None
     if world > 1:
         os.environ.setdefault("GHF_DIST_ROW_STATS", "1")      # plan-time row lists also for the full exchanges: needed vs received rows
         exch = args.exchange if args.dist_mode == "dst" and (args.balance == "rows" or args.exchange == "sparse") else (
@@ -268,8 +269,13 @@ def main():
             exch = min(cand, key=lambda k: cand[k][0])
             exchange_pick = {k: v[0] for k, v in cand.items()}
             runner = cand[exch][1]
+            exchange_why = (f"auto: the fastest of three timed forwards each (max over ranks): "
+                            + ", ".join(f"{k} {v:.2f} ms" for k, v in exchange_pick.items()) + f" -> {exch}")
         else:
             runner = ShardedHyperGNN(model, mode=args.dist_mode, exchange=exch, balance=args.balance)
+            exchange_why = (f"--exchange {args.exchange}" if args.exchange != "auto" else
+                            "edge-balanced slots differ in size: pairwise messages" if args.balance == "edges" else
+                            "edge-range mode: reduce-scatter + all-gather") + f" -> {runner.exchange}"
 
     graphed = model.graphed(x, edge_index, edge_texts) if (args.hip_graph and world == 1) else None
 
@@ -329,7 +335,7 @@ def main():
         links = max(1, world - 1)                         # xGMI: one link per peer
         dist_detail = {
             "mode": runner.mode, "exchange": runner.exchange, "balance": runner.balance, "chunks": runner._spec.chunks,
-            "exchange_candidates_ms": exchange_pick,
+            "exchange_candidates_ms": exchange_pick, "exchange_chosen_because": exchange_why,
             "per_rank": [{"rank": r, "compute_ms": float(v[0]), "exchange_ms": float(v[1]), "exposed_exchange_ms": float(v[2]),
                           "bytes_received_per_forward": float(v[3]),
                           "rows_needed_per_layer": int(v[4]), "rows_received_per_layer": int(v[5]),

@@ -87,6 +87,8 @@ SIGNATURES = {
     "ghf_transpose_batched": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ghf_weights_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ghf_score_pairs_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "ghf_rows_pack": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "ghf_rows_unpack": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "ghf_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "ghf_set_range_flag": (_i32, [_vp]),
 }
@@ -803,3 +805,24 @@ def tail_fwd(agg: torch.Tensor, h: torch.Tensor, ln_gamma: torch.Tensor, ln_beta
     _check(lib.ghf_tail_fwd(_ptr(agg), _ptr(h), _ptr(ln_gamma), _ptr(ln_beta), float(ln_eps), row0, rows, d,
                             _ptr(h_out), _ptr(None if drop is None else _req(drop, torch.float32, "drop")), _stream()), "ghf_tail_fwd")
     return h_out
+
+
+def rows_pack(tables, idx: torch.Tensor) -> torch.Tensor:
+    """The rows `idx` (int64, device) of one or two row-indexed byte tables ([N, row_bytes] uint8 views of one allocation each)
+    as one contiguous message [n, row_bytes (+ extra_bytes)] uint8 — ghf_rows_pack."""
+    rows = tables[0]
+    extra = tables[1] if len(tables) > 1 else None
+    rb, xb = rows.size(1) * rows.element_size(), (extra.size(1) * extra.element_size() if extra is not None else 0)
+    out = torch.empty(idx.numel(), rb + xb, dtype=torch.uint8, device=rows.device)
+    _check(load().ghf_rows_pack(_ptr(rows), rb, _ptr(extra), xb, _ptr(idx), idx.numel(), rows.size(0), _ptr(out), _stream()), "ghf_rows_pack")
+    return out
+
+
+def rows_unpack(tables, idx: torch.Tensor, packed: torch.Tensor) -> None:
+    """ghf_rows_unpack: a received message back to the rows' places in the same tables."""
+    rows = tables[0]
+    extra = tables[1] if len(tables) > 1 else None
+    rb, xb = rows.size(1) * rows.element_size(), (extra.size(1) * extra.element_size() if extra is not None else 0)
+    if packed.numel() != idx.numel() * (rb + xb):
+        raise ValueError(f"rows_unpack: message of {packed.numel()} bytes for {idx.numel()} rows of {rb + xb}")
+    _check(load().ghf_rows_unpack(_ptr(packed), _ptr(idx), idx.numel(), rows.size(0), _ptr(rows), rb, _ptr(extra), xb, _stream()), "ghf_rows_unpack")

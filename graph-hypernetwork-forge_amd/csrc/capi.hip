@@ -366,6 +366,18 @@ int ghf_weights_pack(const float* top, const float* bottom, int transpose, int R
     return launch_weights_pack(top, bottom, transpose, R, d, wlayout, out, (hipStream_t)stream);
 }
 
+int ghf_rows_pack(const void* rows, int64_t row_bytes, const void* extra, int64_t extra_bytes, const int64_t* idx, int64_t n,
+                  int64_t nrows, void* packed, void* stream) {
+    GHF_REQUIRE(rows && idx && packed, "rows_pack: null pointer argument");
+    return launch_rows_pack(false, (void*)rows, row_bytes, (void*)extra, extra_bytes, idx, n, nrows, packed, (hipStream_t)stream);
+}
+
+int ghf_rows_unpack(const void* packed, const int64_t* idx, int64_t n, int64_t nrows, void* rows, int64_t row_bytes, void* extra,
+                    int64_t extra_bytes, void* stream) {
+    GHF_REQUIRE(rows && idx && packed, "rows_unpack: null pointer argument");
+    return launch_rows_pack(true, rows, row_bytes, extra, extra_bytes, idx, n, nrows, (void*)packed, (hipStream_t)stream);
+}
+
 int ghf_score_pairs_fwd(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,
                         int64_t n, int d, float* scores, void* stream) {
     GHF_REQUIRE(a && b && (scores || n == 0), "score_pairs_fwd: null pointer argument");

@@ -159,6 +159,8 @@ int launch_weightgen_batched(int L, const float* text_emb, const float* const* h
                              float* hidden_ws, float* const* W_msg, float* const* W_self, float* const* bias,
                              const float* hidden_drop, hipStream_t stream);
 
+int launch_rows_pack(bool unpack, void* rows, int64_t row_bytes, void* extra, int64_t extra_bytes, const int64_t* idx, int64_t n,
+                     int64_t nrows, void* packed, hipStream_t stream);
 int launch_score_pairs(const float* a, const float* b, const int64_t* ia, const int64_t* ib, int64_t rows_a, int64_t rows_b,
                        int64_t n, int d, float* scores, hipStream_t stream);
 int launch_text_encode(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* E, int V, int C,

@@ -175,6 +175,14 @@ class NativeOps:
         b = hs.view(torch.uint8)
         return [b[: N * 4 * d].view(N, 4 * d), b[N * 4 * d: N * 4 * d + 4 * N].view(N, 4)]
 
+    def pack_rows(self, tables: List[torch.Tensor], idx: torch.Tensor) -> torch.Tensor:
+        """The sparse exchange's message: rows `idx` of every table of `tables` (the split form's rows and scales, or fp32
+        rows), one contiguous [n, bytes] buffer — ghf_rows_pack (csrc/exchange.hip)."""
+        return _native.rows_pack([t.view(torch.uint8).view(t.size(0), -1) for t in tables], idx)
+
+    def unpack_rows(self, tables: List[torch.Tensor], idx: torch.Tensor, packed: torch.Tensor) -> None:
+        _native.rows_unpack([t.view(torch.uint8).view(t.size(0), -1) for t in tables], idx, packed)
+
     def layer_begin(self, model, l: int, weights, h, plan) -> None:
         """Once per layer, before its chunks.  Wide rows (csrc/message_rs.hip): pass 1 over all of this rank's edges —
         it runs in relation order, not by destination chunk; the chunks then only do pass 2 on their rows."""
@@ -257,8 +265,6 @@ class ShardedHyperGNN:
         """Make every rank's slot of chunk c of a row-indexed buffer visible on every rank."""
         if self.profile == "compute":
             return
-        if self.exchange == "sparse" and not self._full_rows:
-            return self._gather_sparse(buf, spec, c)
         if self.exchange in ("pairs", "sparse") or not spec.uniform:
             return self._gather_pairs(buf, spec, c)
         lo, hi = spec.chunk_rows(c)
@@ -286,6 +292,14 @@ class ShardedHyperGNN:
         else:
             parts = [buf[lo + g * spec.S: lo + (g + 1) * spec.S] for g in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)
+
+    def _gather_bufs(self, bufs: List[torch.Tensor], spec: ShardSpec, c: int) -> None:
+        if self.profile == "compute":
+            return
+        if self.exchange == "sparse" and not self._full_rows:
+            return self._gather_sparse(bufs, spec, c)
+        for b in bufs:
+            self._gather_chunk(b, spec, c)
 
     def _gather_pairs(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
         """Pairwise exchange of chunk c: my slot to every peer, every peer's slot from it (one batch of sends/receives).
@@ -315,10 +329,39 @@ class ShardedHyperGNN:
             for lo, hi, t in recvs:
                 buf[lo:hi].copy_(t)
 
-    def _gather_sparse(self, buf: torch.Tensor, spec: ShardSpec, c: int) -> None:
-        """Chunk c, needed rows only: to every peer the rows of my slot it asked for at plan time (packed), from every peer
-        the rows of its slot that my edges read, scattered to their places.  Rows nobody on this rank reads stay stale."""
+    def _gather_sparse(self, bufs: List[torch.Tensor], spec: ShardSpec, c: int) -> None:
+        """Chunk c, needed rows only: to every peer the rows of my slot it asked for at plan time, from every peer the rows of
+        its slot that my edges read, scattered to their places — ONE message per peer for all of `bufs` (the split form's
+        rows and their scales travel together): ops.pack_rows -> pairwise send/recv -> ops.unpack_rows.  Rows nobody on this
+        rank reads stay stale.  (ops without pack_rows — the CPU rehearsal's — go buffer by buffer through torch indexing.)"""
         send_idx, recv_idx = self._sparse["send"][c], self._sparse["recv"][c]
+        if not hasattr(self.ops, "pack_rows") or not bufs[0].is_cuda:
+            for buf in bufs:
+                self._gather_sparse_torch(buf, send_idx, recv_idx)
+            return
+        bounce = self.backend == "gloo"
+        ops, recvs, keep = [], [], []
+        row_bytes = sum(b.size(1) * b.element_size() for b in bufs)
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if send_idx[p].numel():
+                packed = self.ops.pack_rows(bufs, send_idx[p])
+                packed = packed.cpu() if bounce else packed
+                keep.append(packed)
+                ops.append(dist.P2POp(dist.isend, packed, p, group=self.group))
+            if recv_idx[p].numel():
+                t = torch.empty(recv_idx[p].numel(), row_bytes, dtype=torch.uint8, device="cpu" if bounce else bufs[0].device)
+                ops.append(dist.P2POp(dist.irecv, t, p, group=self.group))
+                recvs.append((recv_idx[p], t))
+                self.stats["bytes_recv"] = self.stats.get("bytes_recv", 0.0) + t.numel()
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for idx, t in recvs:
+            self.ops.unpack_rows(bufs, idx, t.to(bufs[0].device) if bounce else t)
+
+    def _gather_sparse_torch(self, buf: torch.Tensor, send_idx, recv_idx) -> None:
         bounce = buf.is_cuda and self.backend == "gloo"
         ops, recvs, keep = [], [], []
         for p in range(self.world):
@@ -417,15 +460,13 @@ class ShardedHyperGNN:
                     ready.record(lane)
                     torch.cuda.set_stream(self._comm_stream)
                     self._comm_stream.wait_event(ready)
-                    for b in bufs:
-                        self._gather_chunk(b, spec, c)
+                    self._gather_bufs(bufs, spec, c)
                 finally:
                     torch.cuda.set_stream(main)
             else:
                 if hi > lo and not skip_compute:
                     compute_rows(lo, hi)
-                for b in bufs:
-                    self._gather_chunk(b, spec, c)
+                self._gather_bufs(bufs, spec, c)
         if on_gpu:
             for s in lanes:
                 if s is not main:

@@ -352,6 +352,16 @@ int ghf_weights_pack(const float* top, const float* bottom, int transpose, int R
 int ghf_score_pairs_fwd(const float* a, const float* b, const int64_t* ia, const int64_t* ib,
                         int64_t rows_a, int64_t rows_b, int64_t n, int d, float* scores, void* stream);
 
+/* ---- the sparse row exchange of the multi-GPU forward (no counterpart in the single-process reference) ----
+ * packed[i] = rows[idx[i]] (row_bytes, a multiple of 16) followed by extra[idx[i]] (extra_bytes, a multiple of 4; extra may be
+ * NULL with extra_bytes = 0), i < n: the listed rows of a [nrows, row_bytes] table (and of a second table indexed alike — the
+ * split form's scales) as one contiguous message; ghf_rows_unpack writes a received message to the rows' places.  idx: int64,
+ * distinct for unpack (entries outside [0, nrows) are skipped).  Bit-exact copies. */
+int ghf_rows_pack(const void* rows, int64_t row_bytes, const void* extra, int64_t extra_bytes, const int64_t* idx, int64_t n,
+                  int64_t nrows, void* packed, void* stream);
+int ghf_rows_unpack(const void* packed, const int64_t* idx, int64_t n, int64_t nrows, void* rows, int64_t row_bytes, void* extra,
+                    int64_t extra_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -226,3 +226,58 @@ def test_shard_spec_covers_all_rows_once():
         for c in range(s0.chunks):                                      # a chunk's slots tile its all-gather slice
             lo, hi = s0.chunk_rows(c)
             assert hi - lo == world * s0.S
+
+
+def _plan_worker(rank, world, port, N, E, R, bn, chunks, ret):
+    """One rank of the eight: everything ShardedHyperGNN.plan_for does at BASELINE config 3's size — shard geometry, this rank's
+    edges, the sparse exchange's row lists through the group — and nothing of the forward."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graph_hypernetwork_forge_amd import synth
+        ei_np, rel = synth.make_graph_arrays(N, E, R, seed=1003)
+        names = synth.relation_names(R)
+        texts = [names[r] for r in rel.tolist()]
+        model = SimpleNamespace(hidden_dim=128)
+        for kw in (dict(exchange="sparse"), dict(exchange="sparse", balance="edges"), dict(mode="edges")):
+            runner = ShardedHyperGNN(model, ops=OracleOps(bn), chunks=chunks, **kw)
+            plan = runner.plan_for(torch.from_numpy(ei_np), texts, N, torch.device("cpu"))
+            spec, sp = runner._spec, runner._sparse
+            info = dict(E=plan.E, owned=sum(hi - lo for lo, hi in spec.owned()), chunks=spec.chunks)
+            if sp is not None:
+                info.update(needed=sp["rows_needed"], other=sp["rows_other"],
+                            sent=sum(int(t.numel()) for c in sp["send"] for t in c), recv=sum(int(t.numel()) for c in sp["recv"] for t in c))
+                for c in range(spec.chunks):
+                    for p in range(world):
+                        lo, hi = spec.slot(c, p)
+                        t = sp["recv"][c][p]
+                        assert p != rank or t.numel() == 0
+                        assert t.numel() == 0 or (int(t.min()) >= lo and int(t.max()) < hi), "a row asked of the wrong owner"
+            ret[(rank, tuple(sorted(kw.items())))] = info
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_plan_config_3_without_computing():
+    """The first 8-GPU run must not die in planning: eight gloo ranks build BASELINE config 3's shards (1 M nodes, 10 M edges,
+    blocks of 384 nodes, four chunks) — row-balanced and edge-balanced destination shards with the sparse exchange's row lists,
+    and the north-star edge ranges — and check what they agreed on.  Plan only: no layer runs."""
+    N, E, R, bn, chunks, world = 1_000_000, 10_000_000, 64, 384, 4, 8
+    ret = mp.Manager().dict()
+    mp.spawn(_plan_worker, args=(world, _free_port(), N, E, R, bn, chunks, ret), nprocs=world, join=True)
+    for kw in (dict(exchange="sparse"), dict(exchange="sparse", balance="edges"), dict(mode="edges")):
+        key = tuple(sorted(kw.items()))
+        infos = [ret[(r, key)] for r in range(world)]
+        assert sum(i["E"] for i in infos) == E                        # every edge on exactly one rank
+        if "mode" in kw:
+            assert max(i["E"] for i in infos) - min(i["E"] for i in infos) <= 1
+            continue
+        assert sum(i["owned"] for i in infos) == N                    # every row owned once
+        assert sum(i["sent"] for i in infos) == sum(i["recv"] for i in infos) == sum(i["needed"] for i in infos)
+        for i in infos:
+            # a uniform random shard of 1.25 M edges reads ~71 % of the other ranks' rows (1 - exp(-1.25)); never more than all
+            assert 0.6 * i["other"] < i["needed"] <= i["other"], i
+            # (equal-row slots of whole blocks: 82 blocks per slot cover 1,007,616 rows, so the last rank's last slot is short — it
+            # holds 5 % fewer edges than the others at this size)
+            assert abs(i["E"] - E / world) < 0.08 * E / world, i
