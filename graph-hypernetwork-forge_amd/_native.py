@@ -492,17 +492,15 @@ def prefer_rs(d: int, R: int) -> bool:
     return d >= 256 or R >= RS_MIN_RELATIONS or os.environ.get("GHF_KERNEL") in ("rs", "rs32")
 
 
-_rs_exact_override = False
-
-
-def rs_exact() -> bool:
-    """GHF_KERNEL=rs32 (or the range guard's fallback): the wide-row layer's pass 1 on fp32 MFMAs (exact fma chain) instead
-    of two fp16 pieces."""
-    return _rs_exact_override or os.environ.get("GHF_KERNEL") == "rs32"
+def rs_exact(plan=None) -> bool:
+    """The wide-row layer's pass 1 on fp32 MFMAs (exact fma chain) instead of two fp16 pieces: GHF_KERNEL=rs32, or a plan
+    built for the exact kernels (GraphPlan.force_exact: the range guard's fallback) — carried by the plan, passed to
+    edge_transform_fwd / segment_tail_fwd explicitly (no process-wide switch)."""
+    return bool(plan is not None and getattr(plan, "force_exact", False)) or os.environ.get("GHF_KERNEL") == "rs32"
 
 
 def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.Tensor, bias: torch.Tensor, Y: torch.Tensor,
-                       h_split: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       h_split: Optional[torch.Tensor] = None, exact: Optional[bool] = None) -> torch.Tensor:
     """Pass 1: per-edge results into Y [E, d] at the edges' destination-order positions (rs: plan.RsPlan; W_msg / W_self
     natural [R, d, d]).  Cuts the weights and — unless the caller has them (`h_split`, from the previous layer's pass 2) —
     the rows of h into their two fp16 pieces first (or transposes the weights, rs32).  Plans whose rows stand for runs of
@@ -511,12 +509,13 @@ def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.T
     lib = load()
     h = _req(h, torch.float32, "h")
     N, d = h.shape
-    if rs_exact() and rs.run_start is not None:
+    exact = rs_exact() if exact is None else (exact or rs_exact())
+    if exact and rs.run_start is not None:
         rs = rs.per_edge()
         Y = rs.scratch(0, d, h.device)
     R = W_msg.size(0)
     Wm, Ws = _req(W_msg, torch.float32, "W_msg"), _req(W_self, torch.float32, "W_self")
-    if rs_exact():
+    if exact:
         WmT, WsT = transpose_batched(Wm), transpose_batched(Ws)      # (named: they must outlive the launch's pointer taking)
         _check(lib.ghf_edge_transform_fwd(_ptr(h), N, d, _ptr(rs.src), _ptr(rs.dst), _ptr(rs.ypos), _ptr(rs.slice_tab),
                                           rs.slice_tab.size(0), _ptr(WmT), _ptr(WsT),
@@ -542,12 +541,13 @@ def edge_transform_fwd(h: torch.Tensor, rs, W_msg: torch.Tensor, W_self: torch.T
 
 def segment_tail_fwd(Y: torch.Tensor, rs, h: Optional[torch.Tensor], ln_gamma, ln_beta, ln_eps: float, h_out: torch.Tensor,
                      row0: int = 0, rows: Optional[int] = None, flags: int = 0,
-                     h_split_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     h_split_out: Optional[torch.Tensor] = None, exact: Optional[bool] = None) -> torch.Tensor:
     """Pass 2: destination sums of Y, mean and tail for rows [row0, row0+rows); `h_split_out` (alloc_split(N, d, SPLIT2H))
     also receives the rows in the form the next layer's pass 1 gathers."""
     N, d = h_out.shape
     rows = N - row0 if rows is None else rows
-    if rs_exact() and rs.run_start is not None:                   # (see edge_transform_fwd)
+    exact = rs_exact() if exact is None else (exact or rs_exact())
+    if exact and rs.run_start is not None:                        # (see edge_transform_fwd)
         rs = rs.per_edge()
         Y = rs.scratch(0, d, h_out.device)
     P = rs.hub_scratch(d) if rs.hub_of is not None else None      # filled by edge_transform_fwd

@@ -105,14 +105,9 @@ def _message(x: torch.Tensor, plan: GraphPlan, W, W_self, bias: torch.Tensor, fl
     if plan.block_nodes == 1 and _native.rs_supported(x.size(1)) and plan.E > 0:
         if plan.rs is None:
             plan.rs = build_rs(plan)
-        old = _native._rs_exact_override
-        _native._rs_exact_override = old or plan.force_exact       # (the guard's fallback: pass 1 on fp32 MFMAs, forward and backward)
-        try:
-            Y = plan.rs.scratch(plan.E, x.size(1), x.device)
-            _native.edge_transform_fwd(x, plan.rs, W, W_self, bias, Y)
-            _native.segment_tail_fwd(Y, plan.rs, None, None, None, 0.0, out, flags=flags)
-        finally:
-            _native._rs_exact_override = old
+        Y = plan.rs.scratch(plan.E, x.size(1), x.device)      # (plan.force_exact — the guard's fallback: pass 1 on fp32 MFMAs, forward and backward)
+        _native.edge_transform_fwd(x, plan.rs, W, W_self, bias, Y, exact=plan.force_exact)
+        _native.segment_tail_fwd(Y, plan.rs, None, None, None, 0.0, out, flags=flags, exact=plan.force_exact)
         return out
     if residual is not None:                 # out = (the pass) + residual, added in the kernel's tail (GHF_FLAG_ADD_H): x_split names
         _native.message_layer_fwd(residual, plan, W, W_self, bias, plan.wlayout, None, None, 0.0, out,      # the gathered rows

@@ -135,7 +135,9 @@ class NativeOps:
 
     def build_plan(self, edge_index, rel_ids, unique, N, d, device, exact: bool = False, **shard) -> GraphPlan:
         if exact:
-            return build_plan(edge_index, rel_ids, unique, N, d, device, exact=True, **shard)
+            plan = build_plan(edge_index, rel_ids, unique, N, d, device, exact=True, **shard)
+            plan.force_exact = True                      # (wide rows: pass 1 on fp32 MFMAs — carried by the plan)
+            return plan
         return build_plan(edge_index, rel_ids, unique, N, d, device,
                           force_generic=_native.prefer_rs(d, len(unique)) and "edge_range" not in shard, **shard)
 
@@ -190,7 +192,7 @@ class NativeOps:
             if plan.rs is None:
                 plan.rs = build_rs(plan)
             W_msg, W_self, bias = weights
-            _native.edge_transform_fwd(h, plan.rs, W_msg, W_self, bias, plan.rs.scratch(plan.E, h.size(1), h.device))
+            _native.edge_transform_fwd(h, plan.rs, W_msg, W_self, bias, plan.rs.scratch(plan.E, h.size(1), h.device), exact=plan.force_exact)
 
     def layer_rows(self, model, l: int, weights, h, h_split, plan, h_out, lo: int, hi: int, h_split_out=None) -> None:
         norm = model.layer_norms[l]
@@ -199,7 +201,7 @@ class NativeOps:
             if plan.rs is None:
                 plan.rs = build_rs(plan)
             _native.segment_tail_fwd(plan.rs.scratch(plan.E, h.size(1), h.device), plan.rs, h, norm.weight.detach(),
-                                     norm.bias.detach(), norm.eps, h_out, row0=lo, rows=hi - lo)
+                                     norm.bias.detach(), norm.eps, h_out, row0=lo, rows=hi - lo, exact=plan.force_exact)
             return
         _native.message_layer_fwd(h, plan, W, W_self, bias, plan.wlayout, norm.weight.detach(), norm.bias.detach(),
                                   norm.eps, h_out, row0=lo, rows=hi - lo, h_split=h_split, h_split_out=h_split_out)
@@ -537,12 +539,7 @@ class ShardedHyperGNN:
                 # ghf_set_range_flag).  The single-GPU forward reruns on the exact fp32 kernels (HyperGNN._forward_exact), and
                 # so does this one — on every rank, since the reduced word is the same everywhere: the same shards planned for
                 # the exact kernels (reference: plain fp32 bmm, hypergnn.py:202,228).
-                old = _native._rs_exact_override
-                _native._rs_exact_override = True
-                try:
-                    out = self._forward_on(node_features, self.plan_for(edge_index, edge_texts, N, device, exact=True))
-                finally:
-                    _native._rs_exact_override = old
+                out = self._forward_on(node_features, self.plan_for(edge_index, edge_texts, N, device, exact=True))
         return out
 
     def _forward_on(self, node_features: torch.Tensor, plan: GraphPlan) -> torch.Tensor:

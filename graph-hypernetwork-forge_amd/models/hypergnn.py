@@ -253,7 +253,7 @@ class HyperGNN(nn.Module):
     # -- range guard of the two-fp16-piece kernels (include/ghf.h: ghf_set_range_flag) ---------------------------
     def _guarded(self, plan: GraphPlan) -> bool:
         pieces = plan.wlayout in _native.SPLIT_LAYOUTS or (plan.block_nodes == 1 and _native.rs_supported(self.hidden_dim)
-                                                          and not _native.rs_exact())
+                                                          and not _native.rs_exact(plan))
         return pieces and _native.range_guard_enabled()
 
     def _forward_exact(self, x: torch.Tensor, plan: GraphPlan, flags: int) -> torch.Tensor:
@@ -261,13 +261,7 @@ class HyperGNN(nn.Module):
         (flags & 2) spans more dynamic range than two fp16 pieces hold (the reference computes in plain fp32,
         hypergnn.py:202,228)."""
         self.last_range_flags = flags
-        ep = exact_plan(plan, self.hidden_dim)
-        old = _native._rs_exact_override
-        _native._rs_exact_override = True
-        try:
-            return self.forward_planned(x, ep, guard=False)
-        finally:
-            _native._rs_exact_override = old
+        return self.forward_planned(x, exact_plan(plan, self.hidden_dim), guard=False)
 
     def _dropping(self) -> bool:
         """Training mode with dropout > 0 (reference :293-294): the forward then takes the recorded path — the layer's tail
@@ -479,7 +473,8 @@ class HyperGNN(nn.Module):
         lo, hi = plan.row_lo, (plan.row_hi or plan.N)
         # rows travel between the layers already cut into fp16 pieces (written by the input projection / pass 2's tail)
         # when one process computes every row; the fp32 MFMA variant gathers h itself
-        pieces = exchange is None and lo == 0 and hi == plan.N and not _native.rs_exact()
+        exact = _native.rs_exact(plan)
+        pieces = exchange is None and lo == 0 and hi == plan.N and not exact
         hs = _native.alloc_split(plan.N, self.hidden_dim, _native.WLAYOUT_SPLIT2H, device) if pieces else None
         hs_next = torch.empty_like(hs) if pieces else None
         h = _native.input_proj_fwd(x, self.input_proj.weight.detach(), self.input_proj.bias.detach(), h_split=hs,
@@ -491,9 +486,9 @@ class HyperGNN(nn.Module):
         for l, (gen, norm) in enumerate(zip(self.weight_generators, self.layer_norms)):
             W_msg, W_self, bias = all_w[l] if all_w is not None else gen.generate(text_embs, _native.WLAYOUT_NATURAL)
             if plan.E > 0:
-                _native.edge_transform_fwd(h, rs, W_msg, W_self, bias, Y, h_split=hs)
+                _native.edge_transform_fwd(h, rs, W_msg, W_self, bias, Y, h_split=hs, exact=exact)
             _native.segment_tail_fwd(Y, rs, h, norm.weight.detach(), norm.bias.detach(), norm.eps, h_next, row0=lo, rows=hi - lo,
-                                     h_split_out=hs_next if pieces and l < last else None)
+                                     h_split_out=hs_next if pieces and l < last else None, exact=exact)
             if exchange is not None:
                 exchange(h_next)
             h, h_next = h_next, h

@@ -126,6 +126,7 @@ def exact_plan(plan: "GraphPlan", d: int) -> "GraphPlan":
         src, dst, rel = plan.edge_arrays()
         plan.exact = build_plan(torch.stack([src, dst]), rel, plan.unique_texts, plan.N, d, plan.sorted_key.device, exact=True)
         plan.exact.row_lo, plan.exact.row_hi = plan.row_lo, plan.row_hi
+        plan.exact.force_exact = True                    # (wide rows: the relation-stationary layer on fp32 MFMAs)
     return plan.exact
 
 
@@ -248,7 +249,7 @@ class GraphPlan:
     train: Optional[object] = None  # autograd.TrainPlan, built by the first forward that records gradients
     rs: Optional[RsPlan] = None     # relation-stationary extras, built by the first wide-row forward
     exact: Optional["GraphPlan"] = None   # the same edges planned for the exact fp32 kernels (range guard fallback)
-    force_exact: bool = False             # recorded passes on this plan run the wide-row layer on fp32 MFMAs (autograd._message)
+    force_exact: bool = False             # this plan's wide-row layer runs on fp32 MFMAs (exact plans: the range guard's fallback)
 
     def edge_arrays(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """(src, dst, relation id) int64 [E] of this plan's edges, decoded from the sorted arrays."""
