@@ -135,14 +135,16 @@ template <class T> __device__ __forceinline__ void bx_tail_st(T* p, T v) {
 #endif
 // Compile-time ablations (GHF_VARIANT=bxexp<mask>, timing only, wrong results; tools/pmc_attr.sh): 1 no B refills, 2 no A-tile
 // DMA, 4 no MFMAs, 8 no fold, 16 no staging writes, 32 no tail, 64 no descriptor pipeline (words / scales / publish / table),
-// 128 one relation's weights for every chunk
+// 128 one relation's weights for every chunk, 256 / 512 the destination / source rows' gathers without memory access
 #ifndef GHF_BXEXP
 #define GHF_BXEXP 0
 #endif
 #ifndef GHF_BX_LATE
-#define GHF_BX_LATE 1         // 1: the destination-row tile of chunk k+1 may land after the barrier, behind a flag the consumers
-                              // wait for before phase 1 (the source-row tile still lands before it); with GHF_BX_DEFER the helpers are
-                              // the longer chain and this takes ~250 cycles per chunk off it (3.21 -> 3.13 ms at C3)
+#define GHF_BX_LATE 0         // 0 (round 4): every gathered tile is waited for (vmcnt(0)) BEFORE the chunk barrier and read behind it — the
+                              // guide's order for LDS-DMA.  1 (rounds 2-3): the destination-row tile of chunk k+1 may land after the barrier,
+                              // behind a flag the consumers wait for before phase 1, and the first phase's first fragments are prefetched:
+                              // measured the same within the box noise in round 4 (2.90-2.93 vs 2.92-2.93 ms at C3, 0.165 vs 0.164 at C2), so
+                              // the shortcut is off
 #endif
 #ifndef GHF_BX_DEFER
 #define GHF_BX_DEFER 1        // 1: a chunk's rows are staged AFTER the next barrier (see the consumers' loop): no hand-shake among the
@@ -159,6 +161,11 @@ template <class T> __device__ __forceinline__ void bx_tail_st(T* p, T v) {
 #endif
 #ifndef GHF_BX64_DEFER
 #define GHF_BX64_DEFER 0     // hidden 64: GHF_BX_DEFER's choice for this size (measured slower there: 0.168 vs 0.164 ms per C2 launch)
+#endif
+#ifndef GHF_BX_SRCNT
+#define GHF_BX_SRCNT 0       // 1: the source rows' gathers non-temporal.  Round 4, same box: 2.92 (1) vs 2.85 ms (0) per C3 launch — a source row
+                             // is gathered ~10 times per layer by different blocks, and with the default policy the Infinity Cache serves part
+                             // of those (the DESTINATION rows non-temporal: 3.12 ms — they live on the caches between their ~10 uses)
 #endif
 #ifndef GHF_BX_IDXWAIT
 #define GHF_BX_IDXWAIT 4     // wait states behind s_set_gpr_idx_on / _off in the fold (header: "The indexing mode's switch"); 0 = round 3
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
     constexpr int skip = SWAP1 ? 2 : SKIP;
     constexpr int P0_IDS = SWAP1 ? 3 : 2;          // which ids the P0 tiles' rows follow (2: source, 3: destination)
     constexpr int P0_HALF = SWAP1 ? 1 : 0;         // the half of the weights (and the row scales) of the P0 phase
-    constexpr bool P0_NT = !SWAP1;   // (a destination row is gathered once per in-edge: default cache policy)
+    constexpr bool P0_NT = GHF_BX_SRCNT && !SWAP1;   // (a destination row is gathered once per in-edge: default cache policy)
     constexpr int BN = C::BN, MTC = C::MTC, CR = C::CR, NPW = C::NPW;
     constexpr bool DEFER = D == 64 ? (GHF_BX64_DEFER != 0) : (GHF_BX_DEFER != 0);
     constexpr int NWV = 8, TW = 4;            // waves per workgroup, per role
@@ -553,7 +560,9 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
                 if (!GHF_BX_LATE && RPP * rb >= rows) continue;
                 const int g = (lane & (LPR - 1)) ^ akey(row);
                 // dead rows: an offset past the end of the buffer (zeros, no memory access)
-                const int voff = row < rows ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : (int)0xFFFFF000u;
+                // (GHF_BXEXP 256 / 512: the destination / source tile's loads all past the buffer — same instructions, no memory access)
+                const bool no_mem = ((GHF_BXEXP & 256) && tile_off >= P1_OFF) || ((GHF_BXEXP & 512) && tile_off < P1_OFF);
+                const int voff = (row < rows && !no_mem) ? (int)((uint32_t)id[i] * (uint32_t)HROW) + (g << 4) : (int)0xFFFFF000u;
                 // a piece past the tile (RBN not a multiple of 4 waves) lands in a scratch KiB
                 const unsigned dst = rb < RBN ? tile_off + (unsigned)rb * 1024u : DUMMY_OFF;
 #pragma unroll
