@@ -66,7 +66,7 @@ def kern_name(plan, d):
         plan.wlayout, "message_pp_kernel" if plan.block_nodes > 1 else "message_generic_kernel")
 
 
-PMC_FILES = {"c3": "r03_message_kernel_pmc.json", "c2": "r03_c2_kernel_pmc.json", "c5": "r03_c5_kernel_pmc.json"}
+PMC_FILES = {"c3": "r04_message_kernel_pmc.json", "c2": "r04_c2_kernel_pmc.json", "c5": "r04_c5_kernel_pmc.json"}
 PMC_SOURCES = {"c3": ["message_bx.hip"], "c2": ["message_bx.hip", "message_pp.hip"], "c5": ["message_rs.hip"]}
 
 
@@ -176,7 +176,7 @@ def roofline_note(wide: bool, plan, d: int) -> str:
     if plan.wlayout == _native.WLAYOUT_SPLIT2H and d == 128:
         return head + ("the block kernel is bound inside the CU: the vector-memory return path (TD) is busy ~80 % of the launch — a "
                        "relation's weights re-streamed from L2 per (block, relation) chunk plus the gathered rows, half of it waiting for "
-                       "L2 / Infinity-Cache data — and the matrix pipe ~34 % (profiles/r03_message_kernel_pipes.json, DESIGN.md §3)")
+                       "L2 / Infinity-Cache data — and the matrix pipe ~34 % (profiles/r04_message_kernel_pipes.json, DESIGN.md §3)")
     if plan.wlayout == _native.WLAYOUT_SPLIT2H:
         return head + ("hidden 64: a quarter of the matrix work per row, so the fixed cost per (block, relation) chunk — barrier, "
                        "hand-shakes, descriptor pipeline, two DMA round trips: ~7 k cycles — decides; two workgroups per CU overlap "

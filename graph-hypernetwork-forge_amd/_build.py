@@ -40,6 +40,9 @@ for _k in ("NPW", "CR", "DEFER"):                         # message_bx.hip, hidd
     _g = _re.search(r"b64%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX64_%s=%s" % (_k, _g.group(1)))
+_r = _re.search(r"rsexp(\d+)", VARIANT)
+if _r:
+    FLAGS.append("-DGHF_RSEXP=" + _r.group(1))          # message_rs.hip pass-1 ablations (timing only)
 _i = _re.search(r"ipexp(\d+)", VARIANT)
 if _i:
     FLAGS.append("-DGHF_IPEXP=" + _i.group(1))          # input_proj.hip timing experiments

@@ -134,6 +134,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // times 256 columns — waves 0-3 the first 128 columns, waves 4-7 the next, all eight reading the one A tile in LDS — so the
 // tile's rows are gathered once per 256 columns instead of once per 128: at d = 256 every gathered row is fetched once, not
 // twice (BASELINE config 5: 91 GB of 205 GB per layer were pass 1's fetches, profiles/r02_c5_kernel_pmc.json).
+#ifndef GHF_RSEXP
+#define GHF_RSEXP 0          // timing-only ablations of pass 1 (wrong results): 1 no MFMAs, 2 no global fetches, 4 no commits to LDS, 8 no fragment reads
+#endif
 template <int KH, int NCT>
 __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
     const char* __restrict__ h_split, int64_t N, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
     struct Stage { i32x4 a[2][GPA], b[2][GPT]; };          // [piece][i]
     Stage st[4];
     auto fetch = [&](int k0, Stage& S) {                   // k0: first contraction index of the step, in [0, 2d)
+        if ((GHF_RSEXP & 2) && k0 > 2 * RS_KH) return;
         const int half = k0 >= d;
         const int kk = half ? k0 - d : k0;
         const char* arow = half ? h_split + (size_t)sv * hrow : urow;
@@ -201,6 +205,7 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
         }
     };
     auto commit = [&](int buf, const Stage& S) {
+        if ((GHF_RSEXP & 4) && buf >= 0) { asm volatile("" :: "v"(S.a[0][0]), "v"(S.b[0][0]), "v"(S.a[1][0]), "v"(S.b[1][0])); return; }
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
                             // consecutive columns of ONE row — 16-byte stores of the results (one column of four rows:
                             // 4-byte stores, four times the store instructions)
                             auto fma = [&](int pa, int pb) {
+                                if (GHF_RSEXP & 1) { asm volatile("" :: "v"(b[c4][pb]), "v"(a[rt][pa])); return; }
                                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[c4][pb]),
                                                                                      __builtin_bit_cast(f16x8, a[rt][pa]), acc[rt][ct], 0, 0, 0);
                             };
