@@ -318,6 +318,215 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
     }
 }
 
+// ---- pass 1, round 4: the same contraction with the tiles gathered by LDS-DMA into a three-deep ring -------------------------
+// edge_transform_h_kernel<32, 2> stages its tiles through registers (96 of them) behind ONE barrier per k-step that all eight
+// waves reach in lockstep: per step every wave waits for its fragment reads, then every wave issues its MFMAs, then every wave
+// writes the next tile — the matrix pipe, the LDS and the vector-memory path take turns (ablations, tools/c5_shard_check.py with
+// GHF_VARIANT=rsexp<mask>: MFMAs, fetches and commits each cost ~0.7 of ~3.6 ms and add up).  Here (d % 256 == 0, 128 rows x
+// 256 columns per workgroup, k-steps of 32, eight waves as before):
+//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4: per-lane 64-bit source address, 1 KiB per wave instruction, the granule
+//     swizzle applied on the source side), TWO steps ahead, into a ring of three buffers — no staging registers, no ds_write;
+//   * a wave's fragment reads run one half-step ahead of its MFMAs (the second half's weights are requested in front of the first
+//     half's products, the next step's first fragments in front of the second half's), so the matrix pipe always has reads in
+//     flight behind it and the two waves of a SIMD interleave without a common phase;
+//   * one barrier per step, in its middle, raw s_barrier (a __syncthreads() would drain the DMAs in flight).  Ordering, by the
+//     count (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"): step s + 1's tile is
+//     complete when every wave has passed vmcnt(6) — its six DMAs for step s + 2, issued at the top of step s, are the only ones
+//     left in flight — and the barrier; it is read behind that barrier only.  Buffer (s + 2) % 3 = (s - 1) % 3 is regathered into
+//     at the top of step s: its last reads (step s - 1's second-half weights) were retired by every wave's lgkmcnt(0) in front of
+//     step s - 1's barrier.
+// The rest — operands, scales, the exact rescale between the row halves, the transposed product and the 16-byte stores — is
+// edge_transform_h_kernel's.
+typedef __attribute__((address_space(3))) void* rs_lptr_t;
+typedef __attribute__((address_space(1))) const void* rs_gptr_t;
+__global__ __launch_bounds__(512, 2) void edge_transform_h3_kernel(
+    const char* __restrict__ h_split, int64_t N, int d, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+    const int64_t* __restrict__ ypos, const int64_t* __restrict__ slice_tab, const char* __restrict__ w2h, int R,
+    const float* __restrict__ bias, const char* __restrict__ x_split, int64_t NX, const float* __restrict__ row_cnt,
+    float* __restrict__ Y) {
+    constexpr int KH = 32, NB = 3;
+    constexpr unsigned A_BYTES = 2 * RS_TM * KH * 2, B_BYTES = 2 * 2 * RS_TN * KH * 2, BUF = A_BYTES + B_BYTES;   // 16 KB + 32 KB
+    extern __shared__ __attribute__((aligned(16))) char rs_lds[];
+    float (*rsc)[RS_TM] = (float (*)[RS_TM])(rs_lds + (size_t)NB * BUF);
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int w = wv & 3, cg = wv >> 2;
+    const int c16 = lane & 15, q = lane >> 4;
+    const unsigned ncol = (unsigned)d / (2 * RS_TN), tile = blockIdx.x / ncol;
+    const int64_t r = slice_tab[3 * (size_t)tile], e0 = slice_tab[3 * (size_t)tile + 1], e1 = slice_tab[3 * (size_t)tile + 2];
+    const int n0 = (int)(blockIdx.x % ncol) * 2 * RS_TN;
+    const size_t hrow = (size_t)4 * d;
+    const float* __restrict__ hscale = (const float*)(h_split + (size_t)N * hrow);
+    auto key = [](int row) { return (0 - (row >> 2)) & 3; };      // granule g of tile row `row` sits at slot g ^ key(row) (see above)
+    // ---- what this wave gathers per step: A pieces wv (hi plane) and wv + 8 (lo plane) = rows 16 wv .. + 15; B pieces: rows
+    // 16 wv .. and 16 (wv + 8) .. of both planes.  Lane l: row l / 4 of the piece, slot l % 4.
+    const int prow = lane >> 2, slot = lane & 3;
+    const int arow_i = 16 * wv + prow;
+    int64_t e = e0 + arow_i;
+    if (e >= e1) e = e1 - 1;                               // rows past the tile's end repeat its last edge (never stored)
+    const int64_t su = src[e], sv = dst[e];               // su < 0: row ~su of x_split (the sum of a run's source rows)
+    const char* __restrict__ urow = su >= 0 ? h_split + (size_t)su * hrow : x_split + (size_t)(~su) * hrow;
+    const char* __restrict__ vrow = h_split + (size_t)sv * hrow;
+    const int ga = (slot ^ key(arow_i)) * 16;              // byte offset of my granule inside a 64-byte k-step of the row
+    if (slot == 0) {
+        const float n = row_cnt ? row_cnt[e] : 1.0f;
+        rsc[0][arow_i] = su >= 0 ? hscale[su] : ((const float*)(x_split + (size_t)NX * hrow))[~su];
+        rsc[1][arow_i] = hscale[sv] * n;
+        rsc[2][arow_i] = n;
+    }
+    const char* __restrict__ wr = w2h + (size_t)r * 8 * d * d;          // [half][piece][n][k] fp16 = 8 d^2 bytes per relation
+    const float wscale = ((const float*)(w2h + (size_t)R * 8 * d * d))[r];
+    const int brow0 = 16 * wv + prow, brow1 = 16 * (wv + 8) + prow;     // B tile rows (= output columns n0 + brow)
+    const int gb0 = (slot ^ key(brow0)) * 16, gb1 = (slot ^ key(brow1)) * 16;
+    const char* __restrict__ bq0 = wr + (size_t)(n0 + brow0) * d * 2 + gb0;
+    const char* __restrict__ bq1 = wr + (size_t)(n0 + brow1) * d * 2 + gb1;
+    const size_t plane_b = (size_t)d * d * 2, half_b = (size_t)2 * d * d * 2;
+    const int half_steps = d / KH, total = 2 * half_steps;
+    auto dma = [&](int step) {                             // six 1 KiB pieces of step `step`'s tile into buffer step % 3
+        if (GHF_RSEXP & 2) return;
+        const int st = step < total ? step : total - 1;    // (past the end: the last step again — the count stays six)
+        const int half = st >= half_steps;
+        const size_t kb = (size_t)(half ? st - half_steps : st) * KH * 2;
+        const char* ap = (half ? vrow : urow) + kb + ga;
+        const unsigned base = (unsigned)(st % NB) * BUF;
+        const unsigned la = base + (unsigned)wv * 1024u;                       // A [plane][128 rows][64 B]: piece wv of plane 0
+        const unsigned lb = base + A_BYTES + (unsigned)wv * 1024u;             // B [plane][256 rows][64 B]
+        const size_t bo = (size_t)half * half_b + kb;
+        __builtin_amdgcn_global_load_lds((rs_gptr_t)ap, (rs_lptr_t)(rs_lds + la), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rs_gptr_t)(ap + (size_t)d * 2), (rs_lptr_t)(rs_lds + la + RS_TM * KH * 2), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rs_gptr_t)(bq0 + bo), (rs_lptr_t)(rs_lds + lb), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rs_gptr_t)(bq1 + bo), (rs_lptr_t)(rs_lds + lb + 8 * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rs_gptr_t)(bq0 + bo + plane_b), (rs_lptr_t)(rs_lds + lb + 2 * RS_TN * KH * 2), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((rs_gptr_t)(bq1 + bo + plane_b), (rs_lptr_t)(rs_lds + lb + 2 * RS_TN * KH * 2 + 8 * 1024), 16, 0, 0);
+    };
+    // ---- fragment reads (through asm: hipcc would order a plain LDS read behind every DMA in flight — vmcnt(0)) ----
+    const unsigned lds0 = (unsigned)(size_t)(rs_lptr_t)rs_lds;
+    unsigned aoff[2], boff[8];                              // byte offsets inside a buffer of my fragments' hi pieces
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int row = 32 * w + 16 * rt + c16;
+        aoff[rt] = (unsigned)row * 64u + (unsigned)((q ^ key(row)) * 16);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const int row = RS_TN * cg + 16 * ct + c16;
+        boff[ct] = A_BYTES + (unsigned)row * 64u + (unsigned)((q ^ key(row)) * 16);
+    }
+    i32x4 a[2][2], b0[4][2], b1[4][2];
+    auto read_a = [&](unsigned buf) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const unsigned ad = lds0 + buf + aoff[rt];
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192" : "=&v"(a[rt][0]), "=&v"(a[rt][1]) : "v"(ad) : "memory");
+        }
+    };
+    auto read_b = [&](unsigned buf, int ch, i32x4 (&b)[4][2]) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const unsigned ad = lds0 + buf + boff[4 * ch + c4];
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16384" : "=&v"(b[c4][0]), "=&v"(b[c4][1]) : "v"(ad) : "memory");
+        }
+    };
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mfma_half = [&](int ch, i32x4 (&b)[4][2]) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int ct = 4 * ch + c4;
+                auto fma = [&](int pa, int pb) {
+                    if (GHF_RSEXP & 1) { asm volatile("" :: "v"(b[c4][pb]), "v"(a[rt][pa])); return; }
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[c4][pb]),
+                                                                         __builtin_bit_cast(f16x8, a[rt][pa]), acc[rt][ct], 0, 0, 0);
+                };
+                fma(1, 0); fma(0, 1);                      // lo*hi, hi*lo
+                fma(0, 0);                                 // hi*hi
+            }
+    };
+    // ---- prologue: steps 0 and 1 requested, step 0 landed, its first fragments requested ----
+    dma(0);
+    dma(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the scales written above)
+    __builtin_amdgcn_s_barrier();
+    read_a(0);
+    read_b(0, 0, b0);
+    for (int s = 0; s < total; ++s) {
+        const unsigned cur = (unsigned)(s % NB) * BUF, nxt = (unsigned)((s + 1) % NB) * BUF;
+        dma(s + 2);
+        read_b(cur, 1, b1);
+        // the first half's fragments (a, b0: requested during the previous step) have landed once only b1's eight reads are out
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                     "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(b0[2][0]), "+v"(b0[2][1]), "+v"(b0[3][0]), "+v"(b0[3][1]) :: "memory");
+        if (s == half_steps) {                             // from the source rows' scale to the destination rows' (exact: a power of two)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = 32 * w + 16 * rt + c16;
+                const float ratio = rsc[0][row] / rsc[1][row];
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) acc[rt][ct] *= ratio;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // (register-only instructions float across asm waits: pin the first half's
+        mfma_half(0, b0);                                  //  products between the fragments' wait and the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        // step s + 1's tile: my pieces have landed (only the six just requested are in flight), my reads of this step's tile are
+        // done; behind the barrier that holds for every wave
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]),
+                     "+v"(b1[2][0]), "+v"(b1[2][1]), "+v"(b1[3][0]), "+v"(b1[3][1]) :: "memory");
+        __builtin_amdgcn_s_barrier();
+        i32x4 a_keep[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a_keep[rt][pl] = a[rt][pl];
+        if (s + 1 < total) {
+            read_a(nxt);                                   // (into a: the second half below multiplies a_keep)
+            read_b(nxt, 0, b0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int ct = 4 + c4;
+                auto fma = [&](int pa, int pb) {
+                    if (GHF_RSEXP & 1) { asm volatile("" :: "v"(b1[c4][pb]), "v"(a_keep[rt][pa])); return; }
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b1[c4][pb]),
+                                                                         __builtin_bit_cast(f16x8, a_keep[rt][pa]), acc[rt][ct], 0, 0, 0);
+                };
+                fma(1, 0); fma(0, 1);
+                fma(0, 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the two clamped requests past the end: nothing may land after the exit)
+    // D (transposed product): lane holds row c16 of a row tile, columns 4q + s of a column tile
+    f32x4 bv[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bv[ct][s4] = bias[(size_t)r * d + n0 + RS_TN * cg + 16 * ct + 4 * q + s4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int row = 32 * w + 16 * rt + c16;
+        const int64_t ee = e0 + row;
+        if (ee < e1) {
+            const float fv = rsc[1][row] * wscale, n = rsc[2][row];
+            float* __restrict__ y = Y + (size_t)ypos[ee] * d + n0 + RS_TN * cg + 4 * q;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                f32x4 o;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) o[s4] = fmaf(acc[rt][ct][s4], fv, bv[ct][s4] * n);
+                *(f32x4*)(y + 16 * ct) = o;
+            }
+        }
+    }
+}
+
 // ghf_weights_pack_rs: natural W_msg, W_self [R][d][d] -> w2h (see above).  One workgroup per relation finds the
 // largest magnitude of both matrices; a second kernel scales, cuts and transposes.
 __global__ __launch_bounds__(256) void rs_wmax_kernel(const float* __restrict__ Wm, const float* __restrict__ Ws, int d,
@@ -622,6 +831,12 @@ int launch_edge_transform_h(const void* h_split, int64_t N, int d, const int64_t
         constexpr size_t lds = (size_t)2 * 2 * 2 * RS_TM * 64 * 2 + 3 * RS_TM * 4;
         GHF_SET_MAX_LDS((edge_transform_h_kernel<64, 1>), lds);
         edge_transform_h_kernel<64, 1><<<grid, 256, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
+                                                                 (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
+    } else if ((d % 256) == 0 && !nct1 && !(getenv("GHF_RS_P1") && atoi(getenv("GHF_RS_P1")) == 2)) {
+        // round 4: tiles by LDS-DMA into a three-deep ring (GHF_RS_P1=2 keeps round 3's register-staged kernel for A/B)
+        constexpr size_t lds = (size_t)3 * (2 * RS_TM * 32 * 2 + 2 * 2 * RS_TN * 32 * 2) + 3 * RS_TM * 4;
+        GHF_SET_MAX_LDS(edge_transform_h3_kernel, lds);
+        edge_transform_h3_kernel<<<grid / 2, 512, lds, stream>>>((const char*)h_split, N, d, src, dst, ypos, slice_tab,
                                                                  (const char*)w2h, R, bias, (const char*)x_split, NX, row_cnt, Y);
     } else if ((d % 256) == 0 && !nct1) {
         constexpr size_t lds = (size_t)2 * 2 * 3 * RS_TM * 32 * 2 + 3 * RS_TM * 4;
