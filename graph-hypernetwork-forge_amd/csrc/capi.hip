@@ -1,5 +1,6 @@
 // capi.hip — the extern "C" surface declared in include/ghf.h.
 #include "common.h"
+#include <vector>
 
 #include <stdlib.h>
 #include <string.h>
@@ -164,6 +165,38 @@ int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows,
     GHF_REQUIRE(N > 0 && d > 0 && d % 4 == 0 && row0 >= 0 && rows >= 0 && row0 + rows <= N, "split_rows: bad shape or row range");
     if (wlayout == GHF_WLAYOUT_SPLIT2H) return launch_split2h_rows(h, N, d, row0, rows, h_split, (hipStream_t)stream);
     return set_err(GHF_EINVAL, "split_rows: layout %d gathers h itself", wlayout);
+}
+
+long long ghf_host_word_ids(const void* words, long long n, int* ids, void** uniq, long long max_uniq) {
+    if (!words || !ids || !uniq || n < 0 || max_uniq <= 0) return -1;
+    size_t cap = 64;
+    while (cap < (size_t)max_uniq * 4) cap <<= 1;
+    std::vector<unsigned long long> key(cap, 0ull);                  // (0 is not a valid object address)
+    std::vector<int> val(cap, -1);
+    const unsigned long long* w = (const unsigned long long*)words;
+    long long k = 0;
+    unsigned long long last = 0;
+    int last_id = -1;
+    for (long long i = 0; i < n; ++i) {
+        const unsigned long long x = w[i];
+        if (x == last && last_id >= 0) { ids[i] = last_id; continue; }
+        size_t h = (size_t)((x >> 4) * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);
+        for (;;) {
+            if (key[h] == x) break;
+            if (val[h] < 0) {
+                if (k >= max_uniq) return -1;
+                key[h] = x;
+                val[h] = (int)k;
+                uniq[k++] = (void*)x;
+                break;
+            }
+            h = (h + 1) & (cap - 1);
+        }
+        last = x;
+        last_id = val[h];
+        ids[i] = last_id;
+    }
+    return k;
 }
 
 int ghf_message_side_output_supported(int d, int block_nodes, int wlayout) {

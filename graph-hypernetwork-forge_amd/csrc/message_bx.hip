@@ -167,6 +167,9 @@ template <class T> __device__ __forceinline__ void bx_tail_st(T* p, T v) {
                              // is gathered ~10 times per layer by different blocks, and with the default policy the Infinity Cache serves part
                              // of those (the DESTINATION rows non-temporal: 3.12 ms — they live on the caches between their ~10 uses)
 #endif
+#ifndef GHF_B_AUX
+#define GHF_B_AUX 0          // cache-policy bits of the consumers' weight-fragment loads (experiment: GHF_VARIANT=baux<n>)
+#endif
 #ifndef GHF_BX_IDXWAIT
 #define GHF_BX_IDXWAIT 4     // wait states behind s_set_gpr_idx_on / _off in the fold (header: "The indexing mode's switch"); 0 = round 3
 #endif
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             for (int t = 0; t < NTW; ++t)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    b[j][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * (NPL * 1024), 0);
+                    b[j][t][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16 + pl * 1024, b_soff(r, ph, t) + j * (NPL * 1024), GHF_B_AUX);
         };
         f32x4 acc[MTC][NTW];
         const int arow = c16 * ROWB;

@@ -165,6 +165,31 @@ def test_relation_ids_first_appearance_order():
     assert ids.dtype == np.int64
 
 
+def test_relation_ids_by_object_identity_equal_the_reference_mapping(monkeypatch):
+    """plan.relation_ids maps long lists by object identity first (ghf_host_word_ids) and must give exactly the reference's
+    value-keyed, first-appearance mapping (models/hypergnn.py:264-268) — also when distinct objects hold equal strings, for
+    tuples, and when the list references more distinct objects than the fast path takes (then it falls back)."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+
+    def reference(texts):
+        unique = list(dict.fromkeys(texts))
+        lut = {t: i for i, t in enumerate(unique)}
+        return unique, np.array([lut[t] for t in texts], dtype=np.int64)
+
+    names = [f"relation_{i:04d}" for i in range(7)]
+    shared = [names[(5 * i * i + 3) % 7] for i in range(20_000)]                         # few objects, many references
+    equal_but_distinct = ["".join(["rel_", str(i % 5)]) for i in range(20_000)]          # 20 k objects, 5 strings
+    mixed = shared[:6000] + equal_but_distinct[:6000] + ["", "caf\u00e9", ""] * 10
+    for texts in (shared, equal_but_distinct, mixed, tuple(shared), shared[:100]):
+        want_u, want_ids = reference(texts)
+        got_u, got_ids = plan_mod.relation_ids(texts)
+        assert got_u == want_u and got_ids.dtype == np.int64 and np.array_equal(got_ids, want_ids)
+    monkeypatch.setattr(plan_mod, "MAX_FAST_OBJECTS", 64)                                  # more objects than the table takes
+    got_u, got_ids = plan_mod.relation_ids(equal_but_distinct)
+    want_u, want_ids = reference(equal_but_distinct)
+    assert got_u == want_u and np.array_equal(got_ids, want_ids)
+
+
 def test_long_relation_lists_are_verified_entry_by_entry():
     """A hit on a list longer than the key's fingerprint covers is confirmed against the snapshot the entry holds
     (plan.same_objects: the lists' item arrays compared bytewise; plan.same_relations: equal strings count as the same
