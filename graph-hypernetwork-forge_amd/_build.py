@@ -32,7 +32,7 @@ if _b:
 _x = _re.search(r"bxexp(\d+)", VARIANT)
 if _x:
     FLAGS.append("-DGHF_BXEXP=" + _x.group(1))         # compile-time ablations of message_bx.hip (timing only)
-for _k in ("NPW", "CR", "LATE", "DEFER", "IDXWAIT", "TAILNT", "SRCNT"):               # message_bx.hip geometry / protocol: e.g. GHF_VARIANT=bxNPW80_bxCR64
+for _k in ("NPW", "CR", "LATE", "DEFER", "IDXWAIT", "TAILNT", "SRCNT", "PRE0"):               # message_bx.hip geometry / protocol: e.g. GHF_VARIANT=bxNPW80_bxCR64
     _g = _re.search(r"bx%s(\d+)" % _k, VARIANT)
     if _g:
         FLAGS.append("-DGHF_BX_%s=%s" % (_k, _g.group(1)))

@@ -1016,7 +1016,10 @@ __global__ __launch_bounds__(512, D == 64 ? 4 : 2) void message_bx_kernel(   // 
             const int* meta = (const int*)(smem + meta_off(k));
             __syncthreads();                               // ---- chunk k
             BX_STAMP(0);
-            constexpr bool PRE_OK = skip == 0 && !YT && GHF_BX_LATE;
+            #ifndef GHF_BX_PRE0
+#define GHF_BX_PRE0 0          // 1: the first phase's first fragments requested right behind the barrier (round 4, LATE off: 2.86 vs 2.83 ms — not kept)
+#endif
+            constexpr bool PRE_OK = skip == 0 && !YT && (GHF_BX_LATE || GHF_BX_PRE0);     // (the source-row tile has landed before the barrier either way)
             constexpr bool PRE0 = PRE_OK, PRE1 = false;        // first / second phase (the second phase's ahead of the unscale: 44 spilled registers)
             using pre0_t = std::integral_constant<bool, PRE0>;
             using pre1_t = std::integral_constant<bool, PRE1>;
