@@ -135,7 +135,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // tile's rows are gathered once per 256 columns instead of once per 128: at d = 256 every gathered row is fetched once, not
 // twice (BASELINE config 5: 91 GB of 205 GB per layer were pass 1's fetches, profiles/r02_c5_kernel_pmc.json).
 #ifndef GHF_RSEXP
-#define GHF_RSEXP 0          // timing-only ablations of pass 1 (wrong results): 1 no MFMAs, 2 no global fetches, 4 no commits to LDS, 8 no fragment reads
+#define GHF_RSEXP 0          // timing-only ablations of pass 1 (wrong results): 1 no MFMAs, 2 no global fetches, 4 no commits to LDS, 16 every gathered row one of 64 (L2-resident)
 #endif
 template <int KH, int NCT>
 __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
@@ -337,6 +337,15 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
 //     step s - 1's barrier.
 // The rest — operands, scales, the exact rescale between the row halves, the transposed product and the 16-byte stores — is
 // edge_transform_h_kernel's.
+// Measured (one GPU's share of C5, 27,118 tiles; tools/c5_shard_check.py under rocprofv3): 4.37 -> 3.95 ms per launch, the whole
+// C5 layer 41.3 -> 38.8 ms.  Ablations of THIS kernel (GHF_VARIANT=rsexp<mask>): without MFMAs 3.14, without the gathers 2.60,
+// with every gathered row one of 64 L2-resident rows 3.21 — its matrix work alone is 1.09 ms at the dense fp16 peak.  What is left
+// is per work item: the descriptor chain in front of the first tile (slice entry -> row ids -> rows: ~5 us of ~37 us, nothing else
+// runs on the CU meanwhile at one 149 KB workgroup per CU) and row latency at two steps of lookahead.  Tried and NOT kept: a
+// persistent form (one workgroup per CU walking the items, rows three / weights two steps ahead in 4 + 3 buffers = all 160 KiB,
+// the next item's descriptors prefetched in stages): as soon as a compiler-visible load is in flight across the loop's merges
+// hipcc puts an s_waitcnt vmcnt(0) in front of the ring's next request — every step drains the ring — and hiding those loads in
+// asm makes the register copies at the merges read them before they land; the descriptors would have to come through LDS.
 typedef __attribute__((address_space(3))) void* rs_lptr_t;
 typedef __attribute__((address_space(1))) const void* rs_gptr_t;
 __global__ __launch_bounds__(512, 2) void edge_transform_h3_kernel(
@@ -364,8 +373,9 @@ __global__ __launch_bounds__(512, 2) void edge_transform_h3_kernel(
     int64_t e = e0 + arow_i;
     if (e >= e1) e = e1 - 1;                               // rows past the tile's end repeat its last edge (never stored)
     const int64_t su = src[e], sv = dst[e];               // su < 0: row ~su of x_split (the sum of a run's source rows)
-    const char* __restrict__ urow = su >= 0 ? h_split + (size_t)su * hrow : x_split + (size_t)(~su) * hrow;
-    const char* __restrict__ vrow = h_split + (size_t)sv * hrow;
+    const char* __restrict__ urow = (GHF_RSEXP & 16) ? h_split + (size_t)(arow_i & 63) * hrow          // (timing: rows that stay in L2)
+                                    : su >= 0 ? h_split + (size_t)su * hrow : x_split + (size_t)(~su) * hrow;
+    const char* __restrict__ vrow = h_split + (size_t)((GHF_RSEXP & 16) ? (arow_i & 63) : sv) * hrow;
     const int ga = (slot ^ key(arow_i)) * 16;              // byte offset of my granule inside a 64-byte k-step of the row
     if (slot == 0) {
         const float n = row_cnt ? row_cnt[e] : 1.0f;
