@@ -46,6 +46,12 @@ if _r:
 _i = _re.search(r"ipexp(\d+)", VARIANT)
 if _i:
     FLAGS.append("-DGHF_IPEXP=" + _i.group(1))          # input_proj.hip timing experiments
+_e = _re.search(r"eoNS(\d)(\d)", VARIANT)
+if _e:                                                   # backward.hip: edge_outer_h's register sets of source / destination rows in flight
+    FLAGS += ["-DGHF_EO_STAGES_A=" + _e.group(1), "-DGHF_EO_STAGES_B=" + _e.group(2)]
+_e = _re.search(r"eoexp(\d+)", VARIANT)
+if _e:
+    FLAGS.append("-DGHF_EOEXP=" + _e.group(1))          # backward.hip: edge_outer_h ablations (timing only)
 if "eopin" in VARIANT:
     FLAGS.append("-DGHF_EO_PIN")
 if "eoslow" in VARIANT:

@@ -20,7 +20,7 @@ from . import _build
 _lock = threading.Lock()
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 GHF_FLAG_NO_TAIL = 1
 GHF_FLAG_RAW_SUM = 2
 GHF_FLAG_ZERO_SRC = 4
@@ -77,8 +77,8 @@ SIGNATURES = {
     "ghf_segment_partial_fwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ghf_segment_tail_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "ghf_edge_outer_supported": (_i32, [_i32]),
-    "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "ghf_edge_outer_scaled": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "ghf_edge_outer": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "ghf_edge_outer_scaled": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "ghf_scale_exp": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "ghf_add3": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -635,10 +635,11 @@ def split_row_scales(split: torch.Tensor, N: int, d: int) -> torch.Tensor:
 
 def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, slice_tab: torch.Tensor,
                slice_off: torch.Tensor, R: int, exact: bool = False, h_scales: Optional[torch.Tensor] = None,
-               G_scales: Optional[torch.Tensor] = None):
+               G_scales: Optional[torch.Tensor] = None, order: Optional[torch.Tensor] = None):
     """(dW [R, 2d, d] = dW_msg stacked on dW_self, db [R, d]) of include/ghf.h: ghf_edge_outer (exact: the fp32 chain at
     every d — a step that fell back to the exact kernels).  h_scales / G_scales: the row scales of the two tensors' split
-    forms (split_row_scales), when the caller holds them: ghf_edge_outer_scaled, same bits without the pass over h and G."""
+    forms (split_row_scales), when the caller holds them: ghf_edge_outer_scaled, same bits without the pass over h and G.
+    order [S] int32: the launch order of the slices (ghf.h; the same bits in any order)."""
     lib = load()
     h, G = _req(h, torch.float32, "h"), _req(G, torch.float32, "G")
     d, ns = h.size(1), slice_tab.size(0)
@@ -647,7 +648,9 @@ def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.T
     dW = torch.empty(R, 2 * d, d, dtype=torch.float32, device=h.device)
     db = torch.empty(R, d, dtype=torch.float32, device=h.device)
     tabs = (_ptr(_req(src, torch.int64, "src")), _ptr(_req(dst, torch.int64, "dst")), _ptr(_req(slice_tab, torch.int64, "slice_tab")),
-            _ptr(_req(slice_off, torch.int64, "slice_off")))
+            _ptr(_req(slice_off, torch.int64, "slice_off")), _ptr(_req(order, torch.int32, "order")) if order is not None else None)
+    if order is not None and order.numel() != ns:
+        raise ValueError("edge_outer: one launch position per slice expected")
     if not exact and h_scales is not None and G_scales is not None and h.size(0) > 0:
         hsc, gsc = _req(h_scales, torch.float32, "h_scales"), _req(G_scales, torch.float32, "G_scales")
         if hsc.numel() != h.size(0) or gsc.numel() != G.size(0):

@@ -47,6 +47,7 @@ class TrainPlan:
     goff: torch.Tensor            # [R+1] int64
     slice_tab: Optional[torch.Tensor] = None   # [S, 3] int64 (relation, first edge, end edge): ghf_edge_outer's work list
     slice_off: Optional[torch.Tensor] = None   # [R+1] int64
+    slice_order: Optional[torch.Tensor] = None # [S] int32: the slices in launch order (by position inside their relation)
     carry: Optional["_SplitCarry"] = None       # split rows handed from one layer's launch to the next
 
 SLICE_EDGES = 4096                # edges per ghf_edge_outer workgroup (a multiple of its 32-edge tile)
@@ -75,6 +76,14 @@ def build_train_plan(edge_index: torch.Tensor, rel_ids: torch.Tensor, fwd: Graph
         if tab:
             tp.slice_tab = torch.tensor(tab, dtype=torch.int64).to(device)
             tp.slice_off = torch.tensor(soff, dtype=torch.int64).to(device)
+            if _EO_ORDER:
+                # Destinations ascend inside a relation, so a slice's place in its relation (as a fraction of the relation's
+                # slices) says which band of destination rows it reads.  Launched band by band — every relation's slice of the
+                # band together — the workgroups in flight share that band's rows of h and G (Infinity Cache) instead of each
+                # relation sweeping all N rows alone.  Same bits: ghf.h, ghf_edge_outer.
+                place = [((k + 0.5) / (soff[r + 1] - soff[r]), r) for r in range(fwd.R) for k in range(soff[r + 1] - soff[r])]
+                order = sorted(range(len(tab)), key=place.__getitem__)
+                tp.slice_order = torch.tensor(order, dtype=torch.int32).to(device)
     return tp
 
 
@@ -148,6 +157,7 @@ class _SplitCarry:
 # training step.  Round 3 (same box, tools/ab_train.sh): 45.0-45.9 ms with, 45.1-45.5 without — the three kernels contend for
 # the same gather path (beside the contraction the self-term pass took 4.8 ms, alone 2.4): off, one stream fewer.
 _EO_SIDE = os.environ.get("GHF_EO_SIDE", "0") != "0"
+_EO_ORDER = os.environ.get("GHF_EO_ORDER", "1") != "0"     # ghf_edge_outer's slices launched band by band (build_train_plan)
 _ONE_PACK = os.environ.get("GHF_BWD_ONE_PACK", "1") != "0"   # the two gradient passes share one packed weight tensor (three pack
                                                              # launches fewer per step; within the box noise of tools/ab_train.sh)
 _SIDE_STREAMS: dict = {}
@@ -214,9 +224,9 @@ class MessageLayerFn(torch.autograd.Function):
                 side = _side_stream(h.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact, **scales)
+                    dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact, order=tp.slice_order, **scales)
             else:
-                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact, **scales)
+                dW, db = _native.edge_outer(h, G, tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, plan.R, exact=plan.force_exact, order=tp.slice_order, **scales)
             d = h.size(1)
             dWm, dWs = dW[:, :d], dW[:, d:]
         else:

@@ -11,6 +11,7 @@
 //   (GHF_FLAG_RAW_SUM): sum_{e->v} G_v Ws[r]^T on the forward plan, sum_{e: src=u} G_v Wm[r]^T on the reversed one.
 // First version: exact fp32 (v_mfma_f32_16x16x4_f32 / vector ALU), deterministic summation orders, any d <= 1024.
 #include "common.h"
+#include <type_traits>
 
 #include <stdlib.h>
 #include <string.h>
@@ -399,7 +400,8 @@ template <int D>
 __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kernel(
     const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
     const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
-    const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b) {
+    const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b,
+    const int32_t* __restrict__ order) {
     constexpr int RG = 2 * D / 64, CG = D / 64, NT = RG * CG * 64;
     constexpr int F4 = D / 4;                             // float4 per row of h / G
     constexpr int LPR = EO_ET * F4 / NT;                  // rows x float4 each thread moves per region and tile
@@ -411,7 +413,8 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int rg = w / CG, cg = w % CG;
     const int c16 = lane & 15, q = lane >> 4;
-    const int64_t e0 = slice_tab[3 * (size_t)blockIdx.x + 1], e1 = slice_tab[3 * (size_t)blockIdx.x + 2];
+    const size_t slice = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
+    const int64_t e0 = slice_tab[3 * slice + 1], e1 = slice_tab[3 * slice + 2];
     const int ntiles = (int)((e1 - e0 + EO_ET - 1) / EO_ET);
 
     f32x4 acc[4][4];
@@ -489,7 +492,7 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
         __syncthreads();
     }
     // partial product: tile (ai, bi) register s is row rg*64 + 4*(4q + s) + ai, column cg*64 + 4*c16 + bi
-    float* P = partial + (size_t)blockIdx.x * 2 * D * D;
+    float* P = partial + slice * 2 * D * D;
 #pragma unroll
     for (int ai = 0; ai < 4; ++ai)
 #pragma unroll
@@ -504,7 +507,7 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < QN; ++k) s += red[k * D + t];
-        partial_b[(size_t)blockIdx.x * D + t] = s;
+        partial_b[slice * D + t] = s;
     }
 }
 
@@ -532,12 +535,12 @@ __global__ __launch_bounds__(256) void edge_outer_reduce_kernel(const float* __r
 template <int D>
 static int edge_outer_launch(const float* h, const float* G, const int64_t* ia, const int64_t* ib, const int64_t* dst, int xa_col,
                              int xb_col, int g_col, int ld, const int64_t* slice_tab, int64_t nslices, float* partial,
-                             float* partial_b, hipStream_t stream) {
+                             float* partial_b, const int32_t* order, hipStream_t stream) {
     constexpr int NT = (2 * D / 64) * (D / 64) * 64;
     const size_t lds = (size_t)2 * EO_ET * 3 * D * sizeof(float);
     GHF_SET_MAX_LDS(edge_outer_kernel<D>, lds);
     edge_outer_kernel<D><<<(unsigned)nslices, NT, lds, stream>>>(h, G, ia, ib, dst, xa_col, xb_col, g_col, ld, slice_tab, partial,
-                                                                 partial_b);
+                                                                 partial_b, order);
     GHF_LAUNCH_CHECK();
     return GHF_OK;
 }
@@ -593,13 +596,24 @@ __global__ __launch_bounds__(256) void rowscale_absmax_kernel(const float* __res
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + blockIdx.y, __float_as_uint(m));
 }
 
+#ifndef GHF_EO_STAGES_A
+#define GHF_EO_STAGES_A 2  // register sets of gathered SOURCE rows in flight in edge_outer_h_kernel (2 or 3)
+#endif
+#ifndef GHF_EO_STAGES_B
+#define GHF_EO_STAGES_B 2  // ... of destination rows (of h and G)
+#endif
+constexpr int EO_STAGES_A = GHF_EO_STAGES_A, EO_STAGES_B = GHF_EO_STAGES_B;
+#ifndef GHF_EOEXP
+#define GHF_EOEXP 0      // timing experiments (wrong results): 1 no products, 2 no row gathers, 4 no cutting / LDS writes, 8 one barrier less
+#endif
 __device__ __forceinline__ unsigned eo_off(int row, int ch) { return 256u * row + 16u * (unsigned)(ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+template <bool OFF32>   // h and G below 4 GB each: 32-bit byte offsets (see Idx)
 __global__ __launch_bounds__(512) void edge_outer_h_kernel(
     const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
     const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
     const int64_t* __restrict__ slice_tab, const unsigned* __restrict__ amax /* bits of max|h|, max|G| */,
-    float* __restrict__ partial, float* __restrict__ partial_b) {
+    float* __restrict__ partial, float* __restrict__ partial_b, const int32_t* __restrict__ order) {
     constexpr int D = 128, RG = 4, CG = 2, NT = 512;
     constexpr int F4 = D / 4;                             // float4 per row of h / G
     constexpr int LPR = EO_ET * F4 / NT;                  // (row, float4) items each thread moves per region and tile: 2
@@ -609,7 +623,8 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int rg = w / CG, cg = w % CG;                   // rows rg*64 .. +63 of [X_src | X_dst], columns cg*64 .. +63 of G
     const int c16 = lane & 15, Q = lane >> 4;
-    const int64_t e0 = slice_tab[3 * (size_t)blockIdx.x + 1], e1 = slice_tab[3 * (size_t)blockIdx.x + 2];
+    const size_t slice = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;   // (launch order: ghf.h, ghf_edge_outer)
+    const int64_t e0 = slice_tab[3 * slice + 1], e1 = slice_tab[3 * slice + 2];
     const int ntiles = (int)((e1 - e0 + EO_ET - 1) / EO_ET);
     const int sx = split2h_shift(__uint_as_float(amax[0])), sg = split2h_shift(__uint_as_float(amax[1]));
     const float upx = pow2f(sx), upg = pow2f(sg);
@@ -625,58 +640,99 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
     for (int j = 0; j < LPR; ++j) bsum[j] = zero4;
 
     // The indices of a tile are loaded a whole step before its rows (two sets), and every load is unconditional (rows past the
-    // slice's end read its last edge's and are zeroed afterwards): straight-line code, so the compiler's counted waits name
-    // exactly the loads they need.  (With `ok ? load : 0` branches each group of loads sat in its own basic block behind an
+    // slice's end read its last edge's and are zeroed when they are cut): straight-line code, so the compiler's counted waits
+    // name exactly the loads they need.  (With `ok ? load : 0` branches each group of loads sat in its own basic block behind an
     // s_waitcnt vmcnt(0): three dependent HBM round trips per tile.)
-    struct Idx { int s[LPR], v[LPR], d[LPR]; bool ok[LPR]; };           // (node ids fit 31 bits: the plan's limit)
-    Idx ix0, ix1;
-    // Rows on their way to LDS: TWO tiles in flight (two register sets).  With one, a tile's rows had one tile's MFMAs (~0.7 us)
-    // to arrive — less than an HBM round trip — and the workgroup waited for them every iteration: 48 KB in flight per CU,
-    // 4.7 TB/s over the chip, the latency-bound rate.
-    struct Stage { f32x4 r[3][LPR]; };
-    Stage st0, st1;
-    auto load_idx = [&](int tile, Idx& I) {
+    // What travels from the index loads to the row loads is each row's BYTE OFFSET (this thread's column quad included) when
+    // h and G are under 4 GB (OFF32; else the row id): the loads then take the tensor's base from scalar registers and one
+    // 32-bit register each — no 64-bit addresses kept in vector registers across the step (NS sets of rows in flight leave none).
+    struct IdxA { unsigned s[LPR]; };                     // (node ids fit 31 bits: the plan's limit)
+    struct IdxB { unsigned v[LPR], d[LPR]; };
+    IdxA ixa[2];
+    IdxB ixb[2];
+    // Rows on their way to LDS, in registers: NSA tiles of source rows and NSB tiles of destination rows (of h and of G) in
+    // flight.  With one set, a tile's rows had one tile's MFMAs (~0.7 us) to arrive and the workgroup waited for them every
+    // iteration (4.7 TB/s over the chip).  With two they have a step and a bit, ~2 us against a loaded round trip of ~2.6 us:
+    // the gathers alone (no products, no cutting) run at 9.5 TB/s of HBM + Infinity Cache — 1.6 ms at C3 — the products and the
+    // cutting alone take as long, and the two together 2.6 ms (round 4's ablations, GHF_EOEXP).  A third set would cover the
+    // round trip, but does not fit: three whole sets (72 registers beside the 64 accumulators, the 40 of a step's fragments
+    // and ~20 LDS addresses) spill ~30 registers inside the loop and the launch takes 3.9 ms instead of 2.9; a third set for the
+    // source rows only (NSA = 3, NSB = 2: the rows that come from HBM, the destination rows of a band of slices launched
+    // together sit in the Infinity Cache) still spills 19, because the trip is then six steps long and hipcc's allocation over
+    // it needs ~45 registers more than over two.  Two and two it stays; what is left is a pipeline that keeps the rows in LDS
+    // (LDS-DMA ring, as message_rs.hip's pass 1) instead of registers.
+    constexpr int NSA = OFF32 ? EO_STAGES_A : 2, NSB = OFF32 ? EO_STAGES_B : 2;
+    f32x4 sa[NSA][LPR], sb[NSB][2][LPR];
+    // (positions inside the slice in 32 bits — a slice holds a few thousand edges; the index arrays from the slice's first edge)
+    const int nedge = (int)(e1 - e0);
+    const unsigned* __restrict__ ja = (const unsigned*)(ia + e0);
+    const unsigned* __restrict__ jb = (const unsigned*)(ib + e0);
+    const unsigned* __restrict__ jd = (const unsigned*)(dst + e0);
+    auto row_ok = [&](int tile, int j) { return tile * EO_ET + (t + NT * j) / F4 < nedge; };
+    const unsigned ldb = (unsigned)ld * 4u;
+    auto edge_of = [&](int tile, int j) { const int e = tile * EO_ET + (t + NT * j) / F4; return e < nedge ? e : nedge - 1; };   // (a slice is never empty)
+    // (little-endian int64 ids below 2^31: the low word is the id)
+    auto load_idx_a = [&](int tile, IdxA& I) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
-            const int64_t e = e0 + (int64_t)tile * EO_ET + (t + NT * j) / F4;
-            I.ok[j] = e < e1;
-            const int64_t ec = I.ok[j] ? e : e1 - 1;      // (e1 > e0: a slice is never empty)
-            I.s[j] = (int)ia[ec];
-            I.v[j] = (int)ib[ec];
-            I.d[j] = (int)dst[ec];
+            const unsigned is = ja[2 * edge_of(tile, j)];
+            I.s[j] = OFF32 ? is * ldb + 4u * xa_col + 16u * ((t + NT * j) % F4) : is;
         }
     };
-    auto gather = [&](Stage& S, const Idx& I) {
+    auto load_idx_b = [&](int tile, IdxB& I) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
-            const int c4 = (t + NT * j) % F4;
-            S.r[0][j] = *(const f32x4*)(h + (size_t)I.s[j] * ld + xa_col + 4 * c4);
-            S.r[1][j] = *(const f32x4*)(h + (size_t)I.v[j] * ld + xb_col + 4 * c4);
-            S.r[2][j] = *(const f32x4*)(G + (size_t)I.d[j] * ld + g_col + 4 * c4);
+            const int ec = edge_of(tile, j);
+            const unsigned c = 16u * ((t + NT * j) % F4);
+            const unsigned iv = jb[2 * ec], id = jd[2 * ec];
+            I.v[j] = OFF32 ? iv * ldb + 4u * xb_col + c : iv;
+            I.d[j] = OFF32 ? id * ldb + 4u * g_col + c : id;
         }
     };
-    auto commit = [&](int buf, const Stage& S, const Idx& I) {   // cut into pieces, row-major images (I: whose rows exist)
-        char* base = eoh_lds + (size_t)buf * 6 * IMG;
+    auto gather_a = [&](f32x4 (&S)[LPR], const IdxA& I) {
 #pragma unroll
         for (int j = 0; j < LPR; ++j) {
-            const int row = (t + NT * j) / F4, c4 = (t + NT * j) % F4;
-            const unsigned o = eo_off(row, c4 >> 1) + 8u * (c4 & 1);
+            if (GHF_EOEXP & 2) { S[j] = (f32x4){1.f * I.s[j], 0.f, 0.f, 0.f}; continue; }
+            if (OFF32) S[j] = *(const f32x4*)((const char*)h + I.s[j]);
+            else S[j] = *(const f32x4*)(h + (size_t)I.s[j] * ld + xa_col + 4 * ((t + NT * j) % F4));
+        }
+    };
+    auto gather_b = [&](f32x4 (&S)[2][LPR], const IdxB& I) {
 #pragma unroll
-            for (int reg = 0; reg < 3; ++reg) {
-                const float up = reg == 2 ? upg : upx;
-                eo_f16x4 hi4, lo4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    _Float16 hi, lo;
-                    split2h((I.ok[j] ? S.r[reg][j][e] : 0.f) * up, hi, lo);
-                    hi4[e] = hi;
-                    lo4[e] = lo;
-                }
-                *(eo_f16x4*)(base + (2 * reg) * IMG + o) = hi4;
-                *(eo_f16x4*)(base + (2 * reg + 1) * IMG + o) = lo4;
+        for (int j = 0; j < LPR; ++j) {
+            if (GHF_EOEXP & 2) { S[0][j] = S[1][j] = (f32x4){1.f * I.v[j], 1.f * I.d[j], 0.f, 0.f}; continue; }
+            if (OFF32) {
+                S[0][j] = *(const f32x4*)((const char*)h + I.v[j]);
+                S[1][j] = *(const f32x4*)((const char*)G + I.d[j]);
+            } else {
+                const int c4 = (t + NT * j) % F4;
+                S[0][j] = *(const f32x4*)(h + (size_t)I.v[j] * ld + xb_col + 4 * c4);
+                S[1][j] = *(const f32x4*)(G + (size_t)I.d[j] * ld + g_col + 4 * c4);
             }
-            if (I.ok[j]) bsum[j] += S.r[2][j];            // db rides along: this thread's column quad, exact fp32
         }
+    };
+    // One (row, column quad) of one of the three tensors cut into its two pieces (unit = 3 j + reg, the order the rows were
+    // requested in): row-major images.  Rows past the slice's end (copies of its last edge's rows) are cut as zeros by a zero
+    // scale (a copy of a row the sums hold anyway: 0 x inf could only put a NaN where the result is no number already).
+    auto commit_unit = [&](int buf, int k, int unit, int tile) __attribute__((always_inline)) {   // tile's rows: sa[k % NSA], sb[k % NSB], k = tile mod TRIP
+        const int j = unit / 3, reg = unit % 3;
+        char* base = eoh_lds + (size_t)buf * 6 * IMG;
+        const int row = (t + NT * j) / F4, c4 = (t + NT * j) % F4;
+        const unsigned o = eo_off(row, c4 >> 1) + 8u * (c4 & 1);
+        const bool ok = row_ok(tile, j);
+        const float up = ok ? (reg == 2 ? upg : upx) : 0.f;
+        const f32x4 x = reg == 0 ? sa[k % NSA][j] : sb[k % NSB][reg - 1][j];
+        eo_f16x4 hi4, lo4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 hi, lo;
+            split2h(x[e] * up, hi, lo);
+            hi4[e] = hi;
+            lo4[e] = lo;
+        }
+        *(eo_f16x4*)(base + (2 * reg) * IMG + o) = hi4;
+        *(eo_f16x4*)(base + (2 * reg + 1) * IMG + o) = lo4;
+        if (reg == 2 && ok) bsum[j] += x;                 // db rides along: this thread's column quad, exact fp32
     };
     // fragment of 16 columns (features fb .. fb+15) x 32 rows (edges) of an image: what lane (Q, c16) needs is column c16, rows
     // 8Q .. 8Q+7 — two transposed reads (rows 8Q.. and 8Q+4..); lane 4q+p of a 16-lane group supplies row r0+q, columns 4p..
@@ -701,57 +757,86 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
         return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    Idx ixc0, ixc1;                                       // (only .ok is read: whose rows of st0 / st1 exist)
-    load_idx(0, ix0);
-    gather(st0, ix0);
-    ixc0 = ix0;
-    load_idx(1, ix1);
-    load_idx(2, ix0);                                     // (before tile 1's rows: the loop is entered with its loads outstanding in
-    gather(st1, ix1);                                     //  the order an iteration leaves them — indices, then rows — or the compiler's
-    ixc1 = ix1;                                           //  merged wait at the loop header drains everything)
-    commit(0, st0, ixc0);
-    __syncthreads();
-    // one tile: its MFMAs on buffer `buf`; `sg` receives tile + 2's rows (indices `ig`, loaded a step ago; `in` receives tile +
-    // 3's, ahead of these row loads in the counter's order), `sc` holds tile + 1's
-    auto step = [&](int tile, int buf, Stage& sg, Idx& okg, const Stage& sc, const Idx& okc, const Idx& ig, Idx& in)
-                    __attribute__((always_inline)) {
-        load_idx(tile + 3, in);
-        gather(sg, ig);
+    // tile k's rows travel in sa[k % NSA] and sb[k % NSB]; before the loop: tiles 0 .. NSA-1 / NSB-1 requested, the indices of
+    // the next tile loaded, tile 0 cut
 #pragma unroll
-        for (int j = 0; j < LPR; ++j) okg.ok[j] = ig.ok[j];
-#ifdef GHF_EO_PIN
-        __builtin_amdgcn_sched_barrier(0);                // (experiment: the loads pinned at the top of the step)
-#endif
-        const char* base = eoh_lds + (size_t)buf * 6 * IMG;
+    for (int k = 0; k < (NSA > NSB ? NSA : NSB); ++k) {
+        if (k < NSB) { load_idx_b(k, ixb[k & 1]); gather_b(sb[k], ixb[k & 1]); }
+        if (k < NSA) { load_idx_a(k, ixa[k & 1]); gather_a(sa[k], ixa[k & 1]); }
+    }
+    load_idx_a(NSA, ixa[NSA & 1]);
+    load_idx_b(NSB, ixb[NSB & 1]);
+#pragma unroll
+    for (int u = 0; u < 3 * LPR; ++u) commit_unit(0, 0, u, 0);
+    __syncthreads();
+    // step K of a trip (tile = first + K, K = tile mod TRIP): this tile's products on image buffer K % 2; the source rows of
+    // tile + NSA and the destination rows of tile + NSB requested into the sets tile's rows left a step ago (their indices came a
+    // step ago; the next ones are loaded ahead of these row loads in the counter's order); tile + 1's rows cut into the other buffer
+    auto step = [&](int tile, auto K_) __attribute__((always_inline)) {
+        constexpr int K = decltype(K_)::value;
+        load_idx_a(tile + NSA + 1, ixa[(K + NSA + 1) & 1]);
+        load_idx_b(tile + NSB + 1, ixb[(K + NSB + 1) & 1]);
+        gather_a(sa[K % NSA], ixa[(K + NSA) & 1]);
+        gather_b(sb[K % NSB], ixb[(K + NSB) & 1]);
+        __builtin_amdgcn_sched_barrier(0);                // (the loads stay at the top of the step: left alone hipcc sinks them to its end)
+        const char* base = eoh_lds + (size_t)(K & 1) * 6 * IMG;
         const char* ximg = base + (rg >> 1) * 2 * IMG;    // rows 0..127 of [X_src | X_dst] are the source image, 128..255 the destination one
         const char* gimg = base + 4 * IMG;
+        // This tile's products, four fragments of X at a time, and between them the next tile's rows cut two units at a time:
+        // the matrix pipe and the vector ALU side by side within every group, and nothing moved from one group to another
+        // (left to itself hipcc hoists every fragment read and address to the top of the step and runs out of registers: NS
+        // sets of rows in flight leave ~40 for all of this).
         eo_f16x8 bh[4], bl[4];
 #pragma unroll
         for (int bi = 0; bi < 4; ++bi) {
             bh[bi] = frag(gimg, cg * 64 + 16 * bi);
             bl[bi] = frag(gimg + IMG, cg * 64 + 16 * bi);
         }
+        static_assert(LPR == 2, "six units over the first three of the four groups");
 #pragma unroll
         for (int ai = 0; ai < 4; ++ai) {
             const int fb = (rg & 1) * 64 + 16 * ai;
             const eo_f16x8 ah = frag(ximg, fb), al = frag(ximg + IMG, fb);
+            if (!(GHF_EOEXP & 1)) {
 #pragma unroll
-            for (int bi = 0; bi < 4; ++bi) {
-                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[bi], acc[ai][bi], 0, 0, 0);
-                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[bi], acc[ai][bi], 0, 0, 0);
-                acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[bi], acc[ai][bi], 0, 0, 0);
+                for (int bi = 0; bi < 4; ++bi) {
+                    acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[bi], acc[ai][bi], 0, 0, 0);
+                    acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[bi], acc[ai][bi], 0, 0, 0);
+                    acc[ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[bi], acc[ai][bi], 0, 0, 0);
+                }
             }
+            if (ai < 3 && !(GHF_EOEXP & 4)) {
+                commit_unit((K & 1) ^ 1, K + 1, 2 * ai, tile + 1);
+                commit_unit((K & 1) ^ 1, K + 1, 2 * ai + 1, tile + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        commit(buf ^ 1, sc, okc);
+        if (GHF_EOEXP & 4) { for (int j = 0; j < LPR; ++j) bsum[j] += sa[(K + 1) % NSA][j] + sb[(K + 1) % NSB][0][j] + sb[(K + 1) % NSB][1][j]; }
+        // (The two halves of a step touch different buffers, so their order is free.  Taken in opposite orders by the two
+        // waves that share a SIMD — one's products beside the other's cutting — the launch got SLOWER: 2.92 -> 3.35 ms at C3,
+        // round 4.  Every wave in the same half at the same time it stays.)
         __syncthreads();
     };
-    for (int tile = 0; tile < ntiles; tile += 2) {
-        step(tile, 0, st0, ixc0, st1, ixc1, ix0, ix1);
-        if (tile + 1 < ntiles) step(tile + 1, 1, st1, ixc1, st0, ixc0, ix1, ix0);
+    // A trip is lcm(NSA, NSB, 2) steps (the sets turn with their periods, the image buffers and the index sets with period 2), all of them
+    // unconditional — a count that is no multiple of it ends in steps on tiles of zeros (rows past the slice's end are cut as
+    // zeros; at most 5 of a slice's ~128 tiles, and slices are cut at multiples of 6 tiles) — so a trip is ONE basic
+    // block.  With a step behind a branch hipcc rotated the loop and the next step's loads met the loads they depend on in one
+    // block: a round trip in the open per trip.
+    constexpr int TRIP = (NSA == 3 || NSB == 3) ? 6 : 2;
+    static_assert(TRIP % NSA == 0 && TRIP % NSB == 0, "two or three sets");
+    for (int tile = 0; tile < ntiles; tile += TRIP) {
+        step(tile + 0, std::integral_constant<int, 0>{});
+        step(tile + 1, std::integral_constant<int, 1>{});
+        if constexpr (TRIP == 6) {
+            step(tile + 2, std::integral_constant<int, 2>{});
+            step(tile + 3, std::integral_constant<int, 3>{});
+            step(tile + 4, std::integral_constant<int, 4>{});
+            step(tile + 5, std::integral_constant<int, 5>{});
+        }
     }
     // partial product: tile (ai, bi) register s is row rg*64 + 16 ai + 4Q + s, column cg*64 + 16 bi + c16
     const float down = pow2f(-sx) * pow2f(-sg);
-    float* P = partial + (size_t)blockIdx.x * 2 * D * D;
+    float* P = partial + slice * 2 * D * D;
 #pragma unroll
     for (int ai = 0; ai < 4; ++ai)
 #pragma unroll
@@ -770,7 +855,7 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
         float s_ = 0.f;
 #pragma unroll
         for (int k = 0; k < NT / F4; ++k) s_ += red[k * D + t];
-        partial_b[(size_t)blockIdx.x * D + t] = s_;
+        partial_b[slice * D + t] = s_;
     }
 }
 
@@ -778,7 +863,7 @@ int edge_outer_supported(int d) { return d == 64 || (d >= 128 && d <= BW_MAX_D &
 
 int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                       const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db,
-                      hipStream_t stream, const float* h_rowscale, const float* G_rowscale) {
+                      hipStream_t stream, const float* h_rowscale, const float* G_rowscale, const int32_t* order) {
     GHF_REQUIRE(edge_outer_supported(d), "edge_outer: d = %d has no tile (64 and multiples of 128 do; use ghf_group_outer)", d);
     GHF_REQUIRE(nslices > 0 && R > 0, "edge_outer: nothing to do");
     const int D = d == 64 ? 64 : 128;                      // tile: [2D, D] of the relation's [2d, d] gradient
@@ -808,15 +893,21 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
             int rc = GHF_OK;
             if (pieces) {
                 constexpr size_t lds = (size_t)2 * 6 * EO_ET * 256;
-                GHF_SET_MAX_LDS(edge_outer_h_kernel, lds);
-                edge_outer_h_kernel<<<(unsigned)nslices, 512, lds, stream>>>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, amax,
-                                                                            partial, partial_b);
+                if ((uint64_t)N * (uint64_t)d * 4u < (1ull << 32)) {
+                    GHF_SET_MAX_LDS(edge_outer_h_kernel<true>, lds);
+                    edge_outer_h_kernel<true><<<(unsigned)nslices, 512, lds, stream>>>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab,
+                                                                                       amax, partial, partial_b, order);
+                } else {
+                    GHF_SET_MAX_LDS(edge_outer_h_kernel<false>, lds);
+                    edge_outer_h_kernel<false><<<(unsigned)nslices, 512, lds, stream>>>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab,
+                                                                                        amax, partial, partial_b, order);
+                }
                 GHF_LAUNCH_CHECK();
             } else
                 rc = D == 128 ? edge_outer_launch<128>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
-                                                       partial_b, stream)
+                                                       partial_b, order, stream)
                               : edge_outer_launch<64>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
-                                                      partial_b, stream);
+                                                      partial_b, order, stream);
             if (rc != GHF_OK) return rc;
             edge_outer_reduce_kernel<<<dim3(gx, (unsigned)R), 256, 0, stream>>>(partial, partial_b, slice_off, D, d, 2 * rb * D, cb * D,
                                                                                dW, rb == 0 ? db : nullptr);

@@ -334,20 +334,21 @@ int ghf_segment_tail_fwd(const float* Y, const int64_t* off, const int32_t* deg_
 int ghf_edge_outer_supported(int d) { return edge_outer_supported(d); }
 
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
-                   const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db,
-                   void* stream) {
+                   const int64_t* slice_off, const int32_t* order, int64_t nslices, int R, int d, int64_t N, float* workspace,
+                   float* dW, float* db, void* stream) {
     GHF_REQUIRE(h && G && src && dst && slice_tab && slice_off && workspace && dW && db, "edge_outer: null pointer argument");
-    return launch_edge_outer(h, G, src, dst, slice_tab, slice_off, nslices, R, d, N, workspace, dW, db, (hipStream_t)stream);
+    return launch_edge_outer(h, G, src, dst, slice_tab, slice_off, nslices, R, d, N, workspace, dW, db, (hipStream_t)stream, nullptr,
+                             nullptr, order);
 }
 
 int ghf_edge_outer_scaled(const float* h, const float* G, const float* h_rowscale, const float* G_rowscale, const int64_t* src,
-                          const int64_t* dst, const int64_t* slice_tab, const int64_t* slice_off, int64_t nslices, int R, int d,
-                          int64_t N, float* workspace, float* dW, float* db, void* stream) {
+                          const int64_t* dst, const int64_t* slice_tab, const int64_t* slice_off, const int32_t* order,
+                          int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db, void* stream) {
     GHF_REQUIRE(h && G && h_rowscale && G_rowscale && src && dst && slice_tab && slice_off && workspace && dW && db,
                 "edge_outer_scaled: null pointer argument");
     GHF_REQUIRE(N > 0, "edge_outer_scaled: N = %lld (the exact chain has no use for row scales: ghf_edge_outer with N <= 0)", (long long)N);
     return launch_edge_outer(h, G, src, dst, slice_tab, slice_off, nslices, R, d, N, workspace, dW, db, (hipStream_t)stream,
-                             h_rowscale, G_rowscale);
+                             h_rowscale, G_rowscale, order);
 }
 
 int ghf_scale_exp(const float* X, int64_t n, const float* log_scale, float* out, void* stream) {

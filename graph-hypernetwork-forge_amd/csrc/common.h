@@ -211,7 +211,7 @@ int edge_outer_supported(int d);
 int launch_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
                       const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db,
                       hipStream_t stream, const float* h_rowscale = nullptr,
-                      const float* G_rowscale = nullptr);
+                      const float* G_rowscale = nullptr, const int32_t* order = nullptr);
 int message_rs_supported(int d);
 int launch_edge_transform(const float* h, int64_t N, int d, const int64_t* src, const int64_t* dst, const int64_t* ypos,
                           const int64_t* slice_tab, int64_t nslices, const float* WmT, const float* WsT, const float* bias,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GHF_ABI_VERSION 14
+#define GHF_ABI_VERSION 15
 
 #define GHF_OK            0
 #define GHF_EINVAL       -1   /* bad argument (shape, alignment, unsupported size) */
@@ -312,18 +312,23 @@ int ghf_group_outer(const float* A, const int64_t* ia, int da, const float* B, c
  * magnitude of h resp. G — found by the call — lifted into [2^13, 2^14)), three v_mfma_f32_16x16x32_f16 per product, fp32
  * accumulation: 22 significand bits relative to each tensor's largest entries.  N <= 0 (or GHF_EDGE_OUTER=exact in the
  * environment) keeps the exact fp32 chain at every d: what the host mirror passes when a training step fell back to the exact
- * kernels (range guard). */
+ * kernels (range guard).
+ * order (or NULL = table order): a permutation of 0 .. nslices-1, the slice each workgroup of the launch takes, in launch
+ * order.  It changes no bit of the result (a slice's partial sums land at the slice's index, the reduction runs in table order)
+ * — only which slices are resident together: with destinations ascending inside a relation, the slices ordered by their
+ * position WITHIN their relation (then by relation) make the workgroups in flight read the same band of destination rows of
+ * h and G, once from HBM and then out of the Infinity Cache, instead of every relation sweeping all rows on its own. */
 int ghf_edge_outer_supported(int d);
 int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int64_t* dst, const int64_t* slice_tab,
-                   const int64_t* slice_off, int64_t nslices, int R, int d, int64_t N /* rows of h and G */, float* workspace,
-                   float* dW, float* db, void* stream);
+                   const int64_t* slice_off, const int32_t* order /* [nslices] or NULL */, int64_t nslices, int R, int d,
+                   int64_t N /* rows of h and G */, float* workspace, float* dW, float* db, void* stream);
 /* The same for a caller that holds the split forms of h and G (ghf_split_rows / the h_split_out of a layer / ghf_tail_bwd's
  * G_split): h_rowscale, G_rowscale [N] = their row scales (the N floats behind the N split rows).  The one scale per tensor is
  * then read off those (2^13 max_row 2^-s(row) has the exponent of the tensor's largest magnitude) instead of by a pass over
  * both tensors: same pieces, same products, same bits as ghf_edge_outer with N > 0.  N > 0 required. */
 int ghf_edge_outer_scaled(const float* h, const float* G, const float* h_rowscale, const float* G_rowscale, const int64_t* src,
-                          const int64_t* dst, const int64_t* slice_tab, const int64_t* slice_off, int64_t nslices, int R, int d,
-                          int64_t N, float* workspace, float* dW, float* db, void* stream);
+                          const int64_t* dst, const int64_t* slice_tab, const int64_t* slice_off, const int32_t* order,
+                          int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db, void* stream);
 /* Elementwise pieces of the backward: out = X * exp(log_scale[0]) (log_scale on the device: the generator's learnable
  * scale, reference weight_generator.py:137-141); out = a + b (+ c when non-NULL); out[i][:] = g[i] * X[i][:] (the two
  * gradients of score_triple, reference hypergnn.py:304-318).  out may alias an input. */

@@ -747,6 +747,15 @@ def test_edge_outer_matches_the_plain_contraction(d, N, E, R):
     dW, db = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
     again = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
     assert torch.equal(dW, again[0]) and torch.equal(db, again[1])   # fixed summation order
+    # the launch order (band by band, build_train_plan) and any other permutation of the slices: the same bits, on the 16-bit
+    # pipe and on the exact fp32 chain
+    S = tp.slice_tab.size(0)
+    assert tp.slice_order is not None and sorted(tp.slice_order.cpu().tolist()) == list(range(S))
+    for order in (tp.slice_order, torch.from_numpy(rng.permutation(S).astype(np.int32)).to(DEV)):
+        for exact in (False, True):
+            base = (dW, db) if not exact else _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R, exact=True)
+            perm = _native.edge_outer(t(h), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R, exact=exact, order=order)
+            assert torch.equal(base[0], perm[0]) and torch.equal(base[1], perm[1])
     if d % 128 == 0:
         # ghf_edge_outer_scaled: the one scale per tensor read off the row scales of the split forms — the same bits
         # (rows scaled apart by 2^20 and a row of zeros: the tensor's scale is its largest row's)

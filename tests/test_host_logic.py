@@ -23,7 +23,7 @@ def test_library_exports_every_symbol_of_the_header():
     assert set(names) == set(_native.SIGNATURES), "include/ghf.h and _native.SIGNATURES disagree"
     for n in names:
         assert hasattr(lib, n), f"libghf_hip.so does not export {n}"
-    assert lib.ghf_abi_version() == _native.ABI_VERSION == 14
+    assert lib.ghf_abi_version() == _native.ABI_VERSION == 15
 
 
 def test_abi_argument_validation_without_a_gpu():
