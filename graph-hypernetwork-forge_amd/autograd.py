@@ -48,6 +48,7 @@ class TrainPlan:
     slice_tab: Optional[torch.Tensor] = None   # [S, 3] int64 (relation, first edge, end edge): ghf_edge_outer's work list
     slice_off: Optional[torch.Tensor] = None   # [R+1] int64
     slice_order: Optional[torch.Tensor] = None # [S] int32: the slices in launch order (by position inside their relation)
+    ident: Optional[tuple] = None               # (arange(N), slice table, slice offsets): InputProjFn's weight gradient as ghf_edge_outer
     carry: Optional["_SplitCarry"] = None       # split rows handed from one layer's launch to the next
 
 SLICE_EDGES = 4096                # edges per ghf_edge_outer workgroup (a multiple of its 32-edge tile)
@@ -157,6 +158,7 @@ class _SplitCarry:
 # training step.  Round 3 (same box, tools/ab_train.sh): 45.0-45.9 ms with, 45.1-45.5 without — the three kernels contend for
 # the same gather path (beside the contraction the self-term pass took 4.8 ms, alone 2.4): off, one stream fewer.
 _EO_SIDE = os.environ.get("GHF_EO_SIDE", "0") != "0"
+_IP_EDGE_OUTER = os.environ.get("GHF_IP_EDGE_OUTER", "1") != "0"   # InputProjFn.backward: dW / db through ghf_edge_outer
 _EO_ORDER = os.environ.get("GHF_EO_ORDER", "1") != "0"     # ghf_edge_outer's slices launched band by band (build_train_plan)
 _ONE_PACK = os.environ.get("GHF_BWD_ONE_PACK", "1") != "0"   # the two gradient passes share one packed weight tensor (three pack
                                                              # launches fewer per step; within the box noise of tools/ab_train.sh)
@@ -327,14 +329,30 @@ class InputProjFn(torch.autograd.Function):
         if split:
             tp.carry.put(h0, hs)
         ctx.save_for_backward(x, W, h0)
+        ctx.tp = tp
         return h0
 
     @staticmethod
     def backward(ctx, g):
         x, W, h0 = ctx.saved_tensors
         dz = _native.relu_mask(g.contiguous().float(), h0)
-        dW = _native.matmul_tn(dz, x)
-        db = _native.colsum(dz)
+        tp, N, d = ctx.tp, x.size(0), x.size(1)
+        if (_IP_EDGE_OUTER and tp is not None and W.size(0) == d and N >= 65536 and _native.load().ghf_edge_outer_supported(d)):
+            # dW^T = x^T dz and db = the column sums of dz are ghf_edge_outer's sums over the "edges" v -> v of one relation
+            # (its [h_src | h_dst] is [x | x]: the second read of a row is an L2 hit): the tall contraction on the matrix pipe
+            # with its slices over all CUs instead of ghf_group_outer + two ghf_colsum (1.0 -> 0.3 ms at C3).  Same two-piece
+            # arithmetic and one-scale-per-tensor contract as the layers' weight gradients (ghf.h); the exact chain when the
+            # step fell back to the exact kernels.
+            if tp.ident is None or tp.ident[0].numel() != N:
+                tab = [(0, a, min(a + SLICE_EDGES, N)) for a in range(0, N, SLICE_EDGES)]
+                tp.ident = (torch.arange(N, dtype=torch.int64, device=x.device), torch.tensor(tab, dtype=torch.int64).to(x.device),
+                            torch.tensor([0, len(tab)], dtype=torch.int64).to(x.device))
+            ids, tab, soff = tp.ident
+            dWt, db1 = _native.edge_outer(x, dz, ids, ids, tab, soff, 1, exact=tp.fwd.force_exact)
+            dW, db = dWt[0, :d].t().contiguous(), db1[0]
+        else:
+            dW = _native.matmul_tn(dz, x)
+            db = _native.colsum(dz)
         dx = None
         if ctx.needs_input_grad[0]:
             # dz W in slabs of rows: one launch holds at most 65,535 x 16 rows of the result (a grid dimension)

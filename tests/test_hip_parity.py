@@ -933,6 +933,35 @@ def test_feature_gradient_beyond_one_launch_of_rows():
     assert bool(torch.isfinite(x.grad).all()) and float(x.grad[1_048_560:].abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("d", [128, 64])
+def test_input_projection_weight_gradient_through_edge_outer(d, monkeypatch):
+    """InputProjFn.backward on a training plan with node_feat_dim == hidden_dim and >= 65,536 rows takes dW / db from
+    ghf_edge_outer over the identity "edges" (autograd.py): against float64 autograd of relu(x W^T + b) (reference
+    hypergnn.py:261), and against the ghf_group_outer chain it replaces."""
+    from graph_hypernetwork_forge_amd import autograd as A
+    N, E, R = 70_000, 90_000, 3
+    ei, rel = synth.make_graph_arrays(N, E, R, seed=31)
+    t = lambda a: torch.from_numpy(a).to(DEV)                       # noqa: E731
+    plan = build_plan(t(ei), t(rel), [""] * R, N, d, DEV)
+    tp = A.build_train_plan(t(ei), t(rel), plan, d, DEV)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x0, W0, b0 = torch.randn(N, d, generator=g), 0.2 * torch.randn(d, d, generator=g), 0.1 * torch.randn(d, generator=g)
+    gout = torch.randn(N, d, generator=g)
+    grads = {}
+    for on in (True, False):
+        monkeypatch.setattr(A, "_IP_EDGE_OUTER", on)
+        W, b = W0.to(DEV).requires_grad_(True), b0.to(DEV).requires_grad_(True)
+        h0 = A.InputProjFn.apply(x0.to(DEV), W, b, tp)
+        (h0 * gout.to(DEV)).sum().backward()
+        grads[on] = (W.grad.cpu().numpy(), b.grad.cpu().numpy())
+    assert tp.ident is not None and tp.ident[0].numel() == N
+    Wr, br = W0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    (torch.relu(x0.double() @ Wr.t() + br) * gout.double()).sum().backward()
+    for on in (True, False):
+        _grad_check(f"input_proj.weight (edge_outer {on})", grads[on][0], Wr.grad.numpy())
+        _grad_check(f"input_proj.bias (edge_outer {on})", grads[on][1], br.grad.numpy())
+
+
 def test_training_side_streams_change_no_bit(monkeypatch):
     """Large graphs train with the generators on a side stream (their backward then runs beside the message layers' gradient
     kernels) and the layers' weight gradients beside the two gradient passes (autograd.py).  Forced on for a small graph, three
