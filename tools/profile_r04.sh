@@ -18,6 +18,7 @@ stats() {  # name, command...
   [ -n "$f" ] && cp "$f" gpurun_out/r04/r04_${name}_kernel_stats.csv
   t=$(find gpurun_out/_kt_$name -name '*kernel_trace.csv' | head -1)
   [ -n "$t" ] && [ "$name" = bench_c3 ] && python3 tools/timeline.py "$t" > gpurun_out/r04/r04_bench_c3_timeline.txt
+  [ -n "$t" ] && [ "$name" = train_c3 ] && python3 tools/timeline_train.py "$t" > gpurun_out/r04/r04_train_c3_timeline.txt
   line=$(grep -E "^\{" gpurun_out/_kt_$name.log | tail -1)
   [ -n "$line" ] && echo "$line" > gpurun_out/r04/r04_${name}_profiled.json      # (an empty line is not written: ADVICE r2)
   rm -rf gpurun_out/_kt_$name
