@@ -1,5 +1,7 @@
 #!/bin/bash
 set -o pipefail
+# (A record of what was run: the build variants these lines name — FOLD*, IDXPAD*, FOLDDRAIN, LDS_PAD ... — were diagnostic
+# code in message_bx.hip that exists only at commit 9c12439; the outcome is profiles/r04_hazard_bisect.txt and DESIGN.md §3.)
 mkdir -p gpurun_out
 S="500000 5000000 32 64"
 run() { name=$1; shift; echo "== $name: $*"; ( "$@" ) > gpurun_out/r4c_$name.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/r4c_$name.log; }
