@@ -39,7 +39,7 @@ SIGNATURES = {
     "ghf_abi_version": (_i32, []),
     "ghf_last_error": (C.c_char_p, []),
     "ghf_host_checksum64": (C.c_uint64, [_vp, _sz, C.c_uint64]),
-    "ghf_host_word_ids": (C.c_longlong, [_vp, C.c_longlong, _vp, _vp, C.c_longlong]),
+    "ghf_host_word_ids": (C.c_longlong, [_vp, C.c_longlong, _vp, _vp, C.c_longlong, C.c_int]),
     "ghf_message_config": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ghf_plan_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32]),
     "ghf_plan_max_chunks": (_i64, [_i64, _i64, _i32, _i32, _i32]),

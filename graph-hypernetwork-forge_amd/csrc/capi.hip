@@ -1,6 +1,8 @@
 // capi.hip — the extern "C" surface declared in include/ghf.h.
 #include "common.h"
 #include <vector>
+#include <thread>
+#include <algorithm>
 
 #include <stdlib.h>
 #include <string.h>
@@ -167,34 +169,126 @@ int ghf_split_rows(const float* h, int64_t N, int d, int64_t row0, int64_t rows,
     return set_err(GHF_EINVAL, "split_rows: layout %d gathers h itself", wlayout);
 }
 
-long long ghf_host_word_ids(const void* words, long long n, int* ids, void** uniq, long long max_uniq) {
-    if (!words || !ids || !uniq || n < 0 || max_uniq <= 0) return -1;
-    size_t cap = 64;
-    while (cap < (size_t)max_uniq * 4) cap <<= 1;
-    std::vector<unsigned long long> key(cap, 0ull);                  // (0 is not a valid object address)
-    std::vector<int> val(cap, -1);
-    const unsigned long long* w = (const unsigned long long*)words;
-    long long k = 0;
-    unsigned long long last = 0;
-    int last_id = -1;
-    for (long long i = 0; i < n; ++i) {
-        const unsigned long long x = w[i];
-        if (x == last && last_id >= 0) { ids[i] = last_id; continue; }
-        size_t h = (size_t)((x >> 4) * 0x9E3779B97F4A7C15ull >> 20) & (cap - 1);
+namespace {
+// open-addressing table of machine words -> dense ids (0 is not a valid object address)
+struct WordTable {
+    std::vector<unsigned long long> key;
+    std::vector<long long> val;
+    size_t mask;
+    explicit WordTable(size_t max_uniq) {
+        size_t cap = 64;
+        while (cap < max_uniq * 4) cap <<= 1;
+        key.assign(cap, 0ull);
+        val.assign(cap, -1);
+        mask = cap - 1;
+    }
+    // id of x, or -1 (then *slot is where it belongs)
+    long long find(unsigned long long x, size_t* slot) const {
+        size_t h = (size_t)((x >> 4) * 0x9E3779B97F4A7C15ull >> 20) & mask;
         for (;;) {
-            if (key[h] == x) break;
-            if (val[h] < 0) {
-                if (k >= max_uniq) return -1;
-                key[h] = x;
-                val[h] = (int)k;
-                uniq[k++] = (void*)x;
-                break;
-            }
-            h = (h + 1) & (cap - 1);
+            if (key[h] == x) return val[h];
+            if (val[h] < 0) { *slot = h; return -1; }
+            h = (h + 1) & mask;
         }
-        last = x;
-        last_id = val[h];
-        ids[i] = last_id;
+    }
+    void put(size_t slot, unsigned long long x, long long id) { key[slot] = x; val[slot] = id; }
+};
+}  // namespace
+
+long long ghf_host_word_ids(const void* words, long long n, long long* ids, void** uniq, long long max_uniq, int threads) {
+    if (!words || !ids || !uniq || n < 0 || max_uniq <= 0) return -1;
+    const unsigned long long* w = (const unsigned long long*)words;
+    // One pass in order over a prefix finds (nearly always all of) the distinct words; the rest of the array is mapped by
+    // `threads` threads against a copy of that table.  A word a thread meets that the prefix did not hold gets a provisional id
+    // (>= PROV, per thread, in the thread's order); those are ranked afterwards — thread by thread, i.e. in array order — and the
+    // few entries that carry one rewritten.  The result equals the sequential pass: ids by first appearance.
+    const long long PROV = 1ll << 40;
+    WordTable tab((size_t)max_uniq);
+    long long k = 0;
+    auto seq = [&](long long a, long long b) -> bool {
+        unsigned long long last = 0;
+        long long last_id = -1;
+        for (long long i = a; i < b; ++i) {
+            const unsigned long long x = w[i];
+            if (x == last && last_id >= 0) { ids[i] = last_id; continue; }
+            size_t slot;
+            long long id = tab.find(x, &slot);
+            if (id < 0) {
+                if (k >= max_uniq) return false;
+                id = k;
+                tab.put(slot, x, id);
+                uniq[k++] = (void*)x;
+            }
+            last = x;
+            last_id = id;
+            ids[i] = id;
+        }
+        return true;
+    };
+    const long long prefix = n < (1ll << 18) || threads <= 1 ? n : (1ll << 16);
+    if (!seq(0, prefix)) return -1;
+    if (prefix == n) return k;
+    const int T = (int)std::min<long long>(threads, (n - prefix + (1ll << 18) - 1) >> 18);
+    std::vector<std::vector<unsigned long long>> fresh(T);             // a thread's new words, in its order
+    std::vector<int> bad(T, 0);
+    const long long per = (n - prefix + T - 1) / T;
+    auto work = [&](int t) {
+        WordTable mine = tab;                                          // (a few KB .. MB: max_uniq * 4 slots)
+        const long long a = prefix + t * per, b = std::min(n, a + per);
+        unsigned long long last = 0;
+        long long last_id = -1;
+        for (long long i = a; i < b; ++i) {
+            const unsigned long long x = w[i];
+            if (x == last && last_id >= 0) { ids[i] = last_id; continue; }
+            size_t slot;
+            long long id = mine.find(x, &slot);
+            if (id < 0) {
+                if ((long long)fresh[t].size() + k >= max_uniq) { bad[t] = 1; return; }
+                id = PROV + (long long)fresh[t].size();
+                mine.put(slot, x, id);
+                fresh[t].push_back(x);
+            }
+            last = x;
+            last_id = id;
+            ids[i] = id;
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    for (int t = 0; t < T; ++t)
+        if (bad[t]) return -1;
+    bool any = false;
+    std::vector<std::vector<long long>> rank(T);
+    for (int t = 0; t < T; ++t) {                                      // threads in array order: first appearance
+        rank[t].resize(fresh[t].size());
+        for (size_t j = 0; j < fresh[t].size(); ++j) {
+            any = true;
+            size_t slot;
+            long long id = tab.find(fresh[t][j], &slot);
+            if (id < 0) {
+                if (k >= max_uniq) return -1;
+                id = k;
+                tab.put(slot, fresh[t][j], id);
+                uniq[k++] = (void*)fresh[t][j];
+            }
+            rank[t][j] = id;
+        }
+    }
+    if (any) {
+        auto fix = [&](int t) {
+            if (fresh[t].empty()) return;
+            const long long a = prefix + t * per, b = std::min(n, a + per);
+            for (long long i = a; i < b; ++i)
+                if (ids[i] >= PROV) ids[i] = rank[t][(size_t)(ids[i] - PROV)];
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(fix, t);
+        fix(0);
+        for (auto& th : pool) th.join();
     }
     return k;
 }

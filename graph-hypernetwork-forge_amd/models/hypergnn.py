@@ -164,7 +164,9 @@ class HyperGNN(nn.Module):
 
     def _plan_lookup(self, edge_index: torch.Tensor, edge_texts: Sequence[str], num_nodes: int, device: torch.device,
                      training: bool = False, defer_check: bool = False):
-        """(plan, check): the cached plan, or a fresh one.  A hit on a relation list too long for the key's fingerprint to
+        """(plan, check, settle): the cached plan, or a fresh one (settle: None, or — with `defer_check` — a callable the caller
+        runs after its launches are enqueued: it waits for the new cache entry's checksums, taken on the cache's threads
+        meanwhile).  A hit on a relation list too long for the key's fingerprint to
         cover whole (plan.FULL_FINGERPRINT_MAX) is confirmed against the snapshot of the list taken when the plan was built
         (plan.same_relations: ~4 ms at 10 M entries) — here, before returning, or, with `defer_check`, by the caller:
         `check` is then a callable () -> bool to run once the forward is enqueued (the host is idle while the GPU works);
@@ -174,16 +176,17 @@ class HyperGNN(nn.Module):
         if plan is not None:
             check = self._plans.verifier(key, edge_texts)
             if check is None:
-                return plan, None
+                return plan, None, None
             if defer_check:
-                return plan, check
+                return plan, check, None
             if check():
-                return plan, None
-        unique, ids = relation_ids(edge_texts)
+                return plan, None, None
+        unique, ids, objects = relation_ids(edge_texts, want_objects=True)
         wide = not training and _native.prefer_rs(self.hidden_dim, len(unique))
         plan = build_plan(edge_index, torch.from_numpy(ids), unique, num_nodes, self.hidden_dim, device, force_generic=wide)
-        self._plans.put(key, plan, edge_index, edge_texts)
-        return plan, None
+        # (defer_check: the caller collects the entry's checksums — taken on the cache's threads beside its launches)
+        taking = self._plans.put(key, plan, edge_index, edge_texts, objects=objects, background=defer_check)
+        return plan, None, (None if taking is None else taking.result)
 
     def graphed(self, node_features: torch.Tensor, edge_index: torch.Tensor, edge_texts: List[str]) -> GraphedForward:
         """Capture ``forward`` for these inputs into a HIP graph (inference only); see GraphedForward."""
@@ -237,16 +240,18 @@ class HyperGNN(nn.Module):
         # The reference maps the strings to ids on every call (:264-268).  Here a cached plan is used at once and, when the
         # list is too long for the cache key to cover, checked entry by entry on the host WHILE the GPU runs the forward; a
         # list edited in place fails the check: fresh plan, forward again.
-        plan, check = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=grad,
-                                        defer_check=not grad)
+        plan, check, settle = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=grad,
+                                                defer_check=not grad)
         if grad:
             return self._forward_recorded(node_features, plan, edge_index)
         # (the check runs on the plan cache's threads, outside the GIL, beside this thread's launches and its wait for the
         # range-guard word; its result is collected before the output is handed back)
         pending = None if check is None else check_pool().submit(check)
         out = self.forward_planned(node_features, plan)
+        if settle is not None:
+            settle()
         if pending is not None and not pending.result():
-            plan, _ = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=False)
+            plan = self._plan_lookup(edge_index, edge_texts, node_features.size(0), device, training=False)[0]
             out = self.forward_planned(node_features, plan)
         return out
 

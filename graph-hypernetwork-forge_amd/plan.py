@@ -25,14 +25,16 @@ from . import _native
 MAX_FAST_OBJECTS = 1 << 16     # relation_ids' fast path: lists that reference at most this many distinct string OBJECTS
 
 
-def relation_ids(edge_texts: Sequence[str]) -> Tuple[List[str], np.ndarray]:
+def relation_ids(edge_texts: Sequence[str], want_objects: bool = False):
     """Unique relation strings in first-appearance order and the per-edge id (int64).
 
     Same mapping as the reference (models/hypergnn.py:264-268); the order of the
     unique list only permutes the generated weights, never the result.  A knowledge graph's list usually references a few
     string objects millions of times: those lists are mapped by object identity first (ghf_host_word_ids over the list's
-    pointer array: one pass at memory speed instead of ten million dict lookups — 0.8 s -> 0.06 s at 10 M edges), and only
-    the distinct objects go through the reference's value-keyed dict."""
+    pointer array, on a few host threads: a pass at memory speed instead of ten million dict lookups — 0.8 s -> 0.005 s at
+    10 M edges), and only the distinct objects go through the reference's value-keyed dict.
+    want_objects: a third result — the distinct string OBJECTS of that fast path (None when it was not taken): while a
+    caller holds them, no other object can take one of their addresses (plan cache: PlanCache.put)."""
     n = len(edge_texts)
     base = _item_array_address(edge_texts) if n >= 4096 else None
     if base is not None:
@@ -41,21 +43,21 @@ def relation_ids(edge_texts: Sequence[str]) -> Tuple[List[str], np.ndarray]:
         except Exception:                                    # (no library: the plain path below needs none)
             lib = None
         if lib is not None:
-            ids32 = np.empty(n, dtype=np.int32)
+            ids = np.empty(n, dtype=np.int64)
             uniq = (ctypes.c_void_p * MAX_FAST_OBJECTS)()
-            k = lib.ghf_host_word_ids(base, n, ids32.ctypes.data, ctypes.addressof(uniq), MAX_FAST_OBJECTS)
+            k = lib.ghf_host_word_ids(base, n, ids.ctypes.data, ctypes.addressof(uniq), MAX_FAST_OBJECTS, _VERIFY_THREADS)
             if k >= 0:
                 objs = [ctypes.cast(uniq[i], ctypes.py_object).value for i in range(k)]      # (alive: the list holds them)
                 unique = list(dict.fromkeys(objs))
-                if len(unique) == k:
-                    return unique, ids32.astype(np.int64)
-                lut = {t: i for i, t in enumerate(unique)}   # distinct objects with equal strings share an id
-                remap = np.fromiter((lut[o] for o in objs), dtype=np.int64, count=k)
-                return unique, remap[ids32]
+                if len(unique) != k:                         # distinct objects with equal strings share an id
+                    lut = {t: i for i, t in enumerate(unique)}
+                    remap = np.fromiter((lut[o] for o in objs), dtype=np.int64, count=k)
+                    ids = remap[ids]
+                return (unique, ids, objs) if want_objects else (unique, ids)
     unique = list(dict.fromkeys(edge_texts))
     lut = {t: i for i, t in enumerate(unique)}
     ids = np.fromiter(map(lut.__getitem__, edge_texts), dtype=np.int64, count=len(edge_texts))
-    return unique, ids
+    return (unique, ids, None) if want_objects else (unique, ids)
 
 
 @dataclass
@@ -531,18 +533,34 @@ class PlanCache:
         self.hits += 1
         return ent[0]
 
-    def put(self, key: Tuple, plan: GraphPlan, edge_index: torch.Tensor, edge_texts: Sequence[str]) -> None:
+    def put(self, key: Tuple, plan: GraphPlan, edge_index: torch.Tensor, edge_texts: Sequence[str], objects=None,
+            background: bool = False):
+        """objects: the list's distinct string objects when relation_ids mapped it by identity (want_objects).  Holding THEM
+        keeps every address of the list's pointer array taken, so the checksums of that array are all a later hit needs: no
+        shallow copy of ten million pointers (19 -> 0 ms of a cold forward at C3).  Without them (strings hashed by value: every
+        entry may be its own object) the entry keeps the copy, as before.
+        background: take the checksums on the cache's threads (GIL-free) and return the future; the caller collects it before
+        it hands anything back (HyperGNN.forward: beside its launches)."""
         # (a list the key's fingerprint covers whole needs no snapshot; forward_ids hands over (ids tensor, texts): no list)
         long_list = isinstance(edge_texts, (list, tuple)) and len(edge_texts) > FULL_FINGERPRINT_MAX and \
             not (len(edge_texts) == 2 and isinstance(edge_texts[0], torch.Tensor))
-        snap = None
-        if long_list:
+        snap, fut = None, None
+        if long_list and objects is not None and _item_array_address(edge_texts) is not None:
+            snap = [None, None, objects]
+            if background:
+                def take(snap=snap, texts=edge_texts):
+                    snap[1] = pointer_checksums(texts)
+                fut = check_pool().submit(take)
+            else:
+                snap[1] = pointer_checksums(edge_texts)
+        elif long_list:
             copy = list(edge_texts)
-            snap = [copy, pointer_checksums(copy)]
+            snap = [copy, pointer_checksums(copy), None]
         self._entries[key] = (plan, edge_index, edge_texts, snap)
         self._entries.move_to_end(key)
         while len(self._entries) > self.capacity:
             self._entries.popitem(last=False)
+        return fut
 
     def verifier(self, key: Tuple, edge_texts: Sequence[str]):
         """None when a hit on `key` needs no further check; else a callable () -> bool (thread-safe, GIL-free for most of its
@@ -555,14 +573,17 @@ class PlanCache:
         def check() -> bool:
             snap = ent[3]
             live = pointer_checksums(edge_texts)
-            if live is not None and live == snap[1]:
+            if live is not None and snap[1] is not None and live == snap[1]:
                 return True
-            if live is None and same_objects(edge_texts, snap[0]):
-                return True
-            if same_relations(edge_texts, snap[0]):
-                copy = list(edge_texts)
-                snap[0], snap[1] = copy, pointer_checksums(copy)
-                return True
+            if snap[0] is not None:                        # (entries that keep a copy of the list: compare with it)
+                if live is None and same_objects(edge_texts, snap[0]):
+                    return True
+                if same_relations(edge_texts, snap[0]):
+                    copy = list(edge_texts)
+                    snap[0], snap[1] = copy, pointer_checksums(copy)
+                    return True
+            # (entries that hold the distinct objects only: some entry now points elsewhere — an edit, or equal strings in
+            # new objects; either way the caller maps the list again, which costs what comparing it would)
             if self._entries.get(key) is ent:
                 del self._entries[key]
             self.hits -= 1

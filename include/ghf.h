@@ -66,10 +66,11 @@ const char* ghf_last_error(void);
  * taken when the plan was built — the per-call string -> id mapping of models/hypergnn.py:264-268 at memory speed. */
 unsigned long long ghf_host_checksum64(const void* p, size_t nbytes, unsigned long long seed);
 /* HOST function: dense ids of an array of `n` machine words (a relation list's object pointers) in first-appearance order —
- * ids[i] = the rank of words[i] among the distinct words by first appearance, uniq[k] = the k-th distinct word.  Returns the
- * number of distinct words, or -1 when there are more than max_uniq (the caller then falls back to hashing the strings).  The
- * reference's dict.fromkeys pass (models/hypergnn.py:264-268) for lists that reference a few string objects many times. */
-long long ghf_host_word_ids(const void* words, long long n, int* ids, void** uniq, long long max_uniq);
+ * ids[i] (int64, what ghf_plan_build takes) = the rank of words[i] among the distinct words by first appearance, uniq[k] = the
+ * k-th distinct word.  Returns the number of distinct words, or -1 when there are more than max_uniq (the caller then falls
+ * back to hashing the strings).  `threads` > 1: the array beyond a prefix is mapped by that many host threads (same result).
+ * The reference's dict.fromkeys pass (models/hypergnn.py:264-268) for lists that reference a few string objects many times. */
+long long ghf_host_word_ids(const void* words, long long n, long long* ids, void** uniq, long long max_uniq, int threads);
 
 /* Which plan geometry and weight layout the message kernel for hidden size d wants.
  * block_nodes == 1 means "CSR by destination" (the generic kernel; chunk_rows == split_chunks == 0 then). */

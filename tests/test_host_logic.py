@@ -190,6 +190,57 @@ def test_relation_ids_by_object_identity_equal_the_reference_mapping(monkeypatch
     assert got_u == want_u and np.array_equal(got_ids, want_ids)
 
 
+def test_relation_ids_on_several_host_threads_keep_first_appearance_order():
+    """ghf_host_word_ids maps the array beyond a prefix on host threads: relations that first appear late — in different
+    threads' stretches, some in more than one — still get their ids by first appearance (reference models/hypergnn.py:264-268)."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    n = 1_600_000
+    names = [f"relation_{i:03d}" for i in range(40)]
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, 8, size=n)                                       # the first eight everywhere
+    for first, rel in ((70_000, 8), (400_000, 9), (400_001, 10), (650_000, 9), (900_000, 11), (1_200_000, 10), (1_599_999, 12)):
+        pick[first] = rel                                                   # late-comers, some met by two threads
+    pick[1_000_000:1_000_050] = np.arange(13, 38).repeat(2)                 # a burst of new ones inside one stretch
+    texts = [names[i] for i in pick.tolist()]
+    unique, ids, objs = plan_mod.relation_ids(texts, want_objects=True)
+    want_u = list(dict.fromkeys(texts))
+    lut = {t: i for i, t in enumerate(want_u)}
+    assert unique == want_u and ids.dtype == np.int64
+    assert np.array_equal(ids, np.array([lut[t] for t in texts], dtype=np.int64))
+    assert objs is not None and all(a is b for a, b in zip(objs, want_u))
+    assert plan_mod.relation_ids(texts[:100], want_objects=True)[2] is None  # short lists: the dict path, no objects
+
+
+def test_cache_entries_that_hold_the_distinct_objects():
+    """PlanCache.put(objects=...): the entry keeps the list's distinct string objects and the checksums of its pointer array
+    (no copy of the list); an untouched list is a hit, any entry that points elsewhere — another relation, or an equal string
+    in a new object — makes the entry stale (the caller maps the list again: reference models/hypergnn.py:264-268)."""
+    from graph_hypernetwork_forge_amd import plan as plan_mod
+    n = plan_mod.FULL_FINGERPRINT_MAX + 50_000
+    names = [f"relation_{i:04d}" for i in range(16)]
+    texts = [names[(7 * i) % 16] for i in range(n)]
+    _, _, objs = plan_mod.relation_ids(texts, want_objects=True)
+    ei, dev = torch.zeros(2, n, dtype=torch.int64), torch.device("cpu")
+    PlanCache.key(ei, texts, 3, 16, dev)                                    # (draws the sampled positions of this length)
+    sampled = set(plan_mod._SAMPLE_IDX[n][0])
+    pos = next(i for i in range(n // 2, n) if i not in sampled)            # an edit the key cannot see
+    for background in (False, True):
+        cache = PlanCache()
+        key = PlanCache.key(ei, texts, 3, 16, dev)
+        fut = cache.put(key, "plan", ei, texts, objects=objs, background=background)
+        assert (fut is not None) == background
+        if fut is not None:
+            fut.result()
+        ent = cache._entries[key]
+        assert ent[3][0] is None and ent[3][2] is objs                      # no copy of the list
+        assert cache.verifier(key, texts)() and cache.get(key) == "plan"
+        old = texts[pos]
+        texts[pos] = "".join(["relation_", old[9:]])                        # an equal string in a new object
+        assert PlanCache.key(ei, texts, 3, 16, dev) == key
+        assert not cache.verifier(key, texts)() and cache.get(key) is None and cache.stale == 1
+        texts[pos] = old
+
+
 def test_long_relation_lists_are_verified_entry_by_entry():
     """A hit on a list longer than the key's fingerprint covers is confirmed against the snapshot the entry holds
     (plan.same_objects: the lists' item arrays compared bytewise; plan.same_relations: equal strings count as the same
