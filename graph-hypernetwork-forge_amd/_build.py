@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(CSRC, "_obj" + ("_" + VARIANT if VARIANT else ""))
 LIB_PATH = os.path.join(PKG_DIR, "libghf_hip" + ("_" + VARIANT if VARIANT else "") + ".so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["capi.hip", "plan.hip", "text_encoder.hip", "score.hip", "backward.hip", "weightgen.hip", "input_proj.hip", "message_generic.hip", "message_pp.hip", "message_bx.hip", "message_rs.hip", "exchange.hip"]
+SOURCES = ["capi.hip", "plan.hip", "text_encoder.hip", "score.hip", "backward.hip", "weightgen.hip", "weightgen_bwd.hip", "input_proj.hip", "message_generic.hip", "message_pp.hip", "message_bx.hip", "message_rs.hip", "exchange.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ghf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 import re as _re

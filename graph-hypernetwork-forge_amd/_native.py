@@ -84,6 +84,9 @@ SIGNATURES = {
     "ghf_rowscale": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "ghf_dot": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "ghf_weightgen_acts": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ghf_weightgen_bwd_supported": (_i32, [_i32, _i32, _i32]),
+    "ghf_weightgen_bwd_workspace_floats": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "ghf_weightgen_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_text_encode_bwd": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_transpose_batched": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "ghf_weights_pack": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -762,6 +765,36 @@ def weightgen_acts(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], 
                                      _ptr(None if hidden_drop is None else _req(hidden_drop, torch.float32, "hidden_drop")), _stream()),
            "ghf_weightgen_acts")
     return acts
+
+
+def weightgen_bwd_supported(T: int, Hh: int, num_hidden: int) -> bool:
+    return bool(load().ghf_weightgen_bwd_supported(T, Hh, num_hidden))
+
+
+def weightgen_bwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], acts: Optional[torch.Tensor],
+                  outs: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], log_scales: torch.Tensor, T: int, Hh: int,
+                  num_hidden: int, d_in: int, d_out: int, log_keep: Optional[torch.Tensor] = None, want_dx: bool = True):
+    """(dparams [one tensor per parameter], dls [3], d text_emb or None): include/ghf.h, ghf_weightgen_bwd — the three heads'
+    backward in three launches.  log_scales: [3] float32 on the device."""
+    lib = load()
+    x = _req(text_emb, torch.float32, "text_emb")
+    R, dev = x.size(0), x.device
+    keep = [_req(p, torch.float32, "weight-generator parameter") for p in head_params]
+    o = [_req(t, torch.float32, "generator output") for t in outs]
+    g = [_req(t, torch.float32, "generator output gradient") for t in grads]
+    ls = _req(log_scales, torch.float32, "log_scales")
+    dparams = [torch.empty_like(p) for p in keep]
+    dls = torch.empty(3, dtype=torch.float32, device=dev)
+    dx = torch.empty(R, T, dtype=torch.float32, device=dev) if want_dx else None
+    ws = torch.empty(lib.ghf_weightgen_bwd_workspace_floats(R, T, Hh, num_hidden, d_in, d_out), dtype=torch.float32, device=dev)
+    arr = lambda ts: (_vp * len(ts))(*[t.data_ptr() for t in ts])       # noqa: E731
+    ls_ptrs = (_vp * 3)(*[ls.data_ptr() + 4 * k for k in range(3)])
+    dls_ptrs = (_vp * 3)(*[dls.data_ptr() + 4 * k for k in range(3)])
+    _check(lib.ghf_weightgen_bwd(_ptr(x), arr(keep), _ptr(None if acts is None else _req(acts, torch.float32, "acts")), arr(o), arr(g),
+                                 ls_ptrs, R, T, Hh, num_hidden, d_in, d_out,
+                                 _ptr(None if log_keep is None else _req(log_keep, torch.float32, "log_keep")), arr(dparams), dls_ptrs,
+                                 _ptr(dx), _ptr(ws), _stream()), "ghf_weightgen_bwd")
+    return dparams, dls, dx
 
 
 def text_encode_bwd(ids: torch.Tensor, lens: torch.Tensor, char_emb: torch.Tensor, W: torch.Tensor, te: torch.Tensor,

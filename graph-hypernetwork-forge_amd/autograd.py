@@ -158,6 +158,8 @@ class _SplitCarry:
 # training step.  Round 3 (same box, tools/ab_train.sh): 45.0-45.9 ms with, 45.1-45.5 without — the three kernels contend for
 # the same gather path (beside the contraction the self-term pass took 4.8 ms, alone 2.4): off, one stream fewer.
 _EO_SIDE = os.environ.get("GHF_EO_SIDE", "0") != "0"
+_WG_FUSED_BWD = int(os.environ.get("GHF_WG_FUSED_BWD", "1"))       # WeightGeneratorFn.backward through ghf_weightgen_bwd: 0 never, 1 small generators, 2 always
+WG_FUSED_MAX = 1 << 18            # ... "small": relations x d_in x d_out (config 2: 2^17, config 3: 2^20)
 _IP_EDGE_OUTER = os.environ.get("GHF_IP_EDGE_OUTER", "1") != "0"   # InputProjFn.backward: dW / db through ghf_edge_outer
 _EO_ORDER = os.environ.get("GHF_EO_ORDER", "1") != "0"     # ghf_edge_outer's slices launched band by band (build_train_plan)
 _ONE_PACK = os.environ.get("GHF_BWD_ONE_PACK", "1") != "0"   # the two gradient passes share one packed weight tensor (three pack
@@ -286,6 +288,16 @@ class WeightGeneratorFn(torch.autograd.Function):
         x, ls = ctx.saved_tensors[0], ctx.saved_tensors[1]
         outs, params = ctx.saved_tensors[2:5], ctx.saved_tensors[5:]
         R, nl = x.size(0), nh + 1
+        if (_WG_FUSED_BWD and (_WG_FUSED_BWD > 1 or R * d_in * d_out <= WG_FUSED_MAX) and all(g is not None for g in grads)
+                and _native.weightgen_bwd_supported(T, Hh, nh)):
+            # all heads, all layers: three launches (csrc/weightgen_bwd.hip) instead of ~68.  For small generators only: the
+            # three kernels are chains of short latency-bound phases (0.1 ms per call at BASELINE configs 1 and 2, 0.25 ms at
+            # config 3) — a win where the step is launch latencies (config 1: 4.7 -> 2.4 ms per step), a loss where the ~68
+            # small launches hide on the side stream beside the gradient passes (config 3: 42.1 -> 42.9 ms).
+            dparams, dls3, dx = _native.weightgen_bwd(x, [p.detach() for p in params], ctx.acts, [o.view(R, -1) for o in outs],
+                                                      [g.contiguous().float().view(R, -1) for g in grads], ls, T, Hh, nh, d_in, d_out,
+                                                      log_keep=ctx.log_keep, want_dx=ctx.needs_input_grad[1])
+            return (None, dx, dls3[0:1], dls3[1:2], dls3[2:3], *dparams)
         dls: List[Optional[torch.Tensor]] = []
         dparams: List[Optional[torch.Tensor]] = [None] * len(params)
         dxs: List[torch.Tensor] = []
@@ -344,7 +356,8 @@ class InputProjFn(torch.autograd.Function):
             # arithmetic and one-scale-per-tensor contract as the layers' weight gradients (ghf.h); the exact chain when the
             # step fell back to the exact kernels.
             if tp.ident is None or tp.ident[0].numel() != N:
-                tab = [(0, a, min(a + SLICE_EDGES, N)) for a in range(0, N, SLICE_EDGES)]
+                step = min(SLICE_EDGES, max(256, (N // 1024 + 31) // 32 * 32))       # ~1,000 slices: all CUs also at 10^5 rows
+                tab = [(0, a, min(a + step, N)) for a in range(0, N, step)]
                 tp.ident = (torch.arange(N, dtype=torch.int64, device=x.device), torch.tensor(tab, dtype=torch.int64).to(x.device),
                             torch.tensor([0, len(tab)], dtype=torch.int64).to(x.device))
             ids, tab, soff = tp.ident

@@ -477,6 +477,22 @@ int ghf_weightgen_acts(const float* text_emb, const float* const* head_params, i
     return launch_weightgen_acts(text_emb, head_params, R, T, Hh, num_hidden, acts, hidden_drop, (hipStream_t)stream);
 }
 
+int ghf_weightgen_bwd_supported(int T, int Hh, int num_hidden) { return weightgen_bwd_supported(T, Hh, num_hidden); }
+
+size_t ghf_weightgen_bwd_workspace_floats(int R, int T, int Hh, int num_hidden, int d_in, int d_out) {
+    return weightgen_bwd_workspace_floats(R, T, Hh, num_hidden, d_in, d_out);
+}
+
+int ghf_weightgen_bwd(const float* text_emb, const float* const* head_params, const float* acts, const float* const* outs,
+                      const float* const* grads, const float* const* log_scales, int R, int T, int Hh, int num_hidden, int d_in,
+                      int d_out, const float* log_keep, float* const* dparams, float* const* dls, float* d_text_emb,
+                      float* workspace, void* stream) {
+    GHF_REQUIRE(text_emb && head_params && outs && grads && log_scales && dparams && dls && workspace,
+                "weightgen_bwd: null pointer argument");
+    return launch_weightgen_bwd(text_emb, head_params, acts, outs, grads, log_scales, R, T, Hh, num_hidden, d_in, d_out, log_keep,
+                                dparams, dls, d_text_emb, workspace, (hipStream_t)stream);
+}
+
 int ghf_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,
                         const float* W, int T, const float* te, const float* dte, float* workspace, float* d_char_emb,
                         float* dW, float* db, void* stream) {

@@ -228,6 +228,12 @@ int launch_segment_tail(const float* Y, const int64_t* off, const int32_t* deg_o
                         const float* h, const float* g, const float* b, float eps, int64_t row0, int64_t rows, int d,
                         float* h_out, void* h_split_out, int64_t n_split, int flags, hipStream_t stream);
 int launch_dot(const float* X, const float* Y, int64_t n, float* workspace, float* out, hipStream_t stream);
+int weightgen_bwd_supported(int T, int Hh, int num_hidden);
+size_t weightgen_bwd_workspace_floats(int R, int T, int Hh, int num_hidden, int d_in, int d_out);
+int launch_weightgen_bwd(const float* text_emb, const float* const* head_params, const float* acts, const float* const* outs,
+                         const float* const* grads, const float* const* log_scales, int R, int T, int Hh, int num_hidden, int d_in,
+                         int d_out, const float* log_keep, float* const* dparams, float* const* dls, float* dx, float* workspace,
+                         hipStream_t stream);
 int launch_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
                           float* acts, const float* hidden_drop, hipStream_t stream);
 int launch_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* E, int V, int C, const float* W,

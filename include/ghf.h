@@ -347,6 +347,20 @@ int ghf_dot(const float* X, const float* Y, int64_t n, float* workspace, float* 
  * acts[head][layer][r][Hh], layer = 0 .. num_hidden-1 (post-ReLU).  Same head_params as ghf_weightgen_fwd. */
 int ghf_weightgen_acts(const float* text_emb, const float* const* head_params, int R, int T, int Hh, int num_hidden,
                        float* acts, const float* hidden_drop /* or NULL */, void* stream);
+/* Backward of ghf_weightgen_fwd with GHF_WLAYOUT_NATURAL outputs (reference models/weight_generator.py:96-143 under plain
+ * autograd), all three heads and all their layers in three launches.  outs[k] / grads[k] (k = message matrices, self matrices,
+ * biases): the forward's outputs [R, d_in*d_out] (k < 2) / [R, d_out] and dL/d of them; log_scales[k]: the heads' log-scales
+ * (device, 1 float each); acts: ghf_weightgen_acts' result; log_keep: NULL, or log(1/(1-p)) (device) when acts are post-dropout.
+ * Writes dparams (one buffer per entry of head_params: dL/dW [out, in] and dL/db [out] of every layer), dls[k] (1 float each,
+ * device: dL/d log-scale) and d_text_emb [R, T] (or NULL).  Exact fp32, fixed summation order.  text_dim and hidden_dim up to
+ * 256 (ghf_weightgen_bwd_supported; wider generators: the per-operation chain — ghf_dot, ghf_scale_exp, ghf_relu_mask,
+ * ghf_group_outer, ghf_colsum).  workspace: ghf_weightgen_bwd_workspace_floats floats. */
+int ghf_weightgen_bwd_supported(int T, int Hh, int num_hidden);
+size_t ghf_weightgen_bwd_workspace_floats(int R, int T, int Hh, int num_hidden, int d_in, int d_out);
+int ghf_weightgen_bwd(const float* text_emb, const float* const* head_params, const float* acts, const float* const* outs,
+                      const float* const* grads, const float* const* log_scales, int R, int T, int Hh, int num_hidden, int d_in,
+                      int d_out, const float* log_keep, float* const* dparams, float* const* dls, float* d_text_emb,
+                      float* workspace, void* stream);
 /* Backward of ghf_text_encode_fwd: given te = its output and dte = dL/dte, writes dL/dchar_emb [V,C], dL/dW [T,C],
  * dL/db [T] (overwritten, fixed summation order).  workspace: 2*U*C + U*T floats. */
 int ghf_text_encode_bwd(const int32_t* ids, const int32_t* lens, int U, int Lmax, const float* char_emb, int V, int C,

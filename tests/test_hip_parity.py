@@ -820,10 +820,17 @@ def _grad_check(name, got, want, rtol=2e-4, l2=5e-5):
 
 @pytest.mark.parametrize("T,Hh,nh,d_in,d_out,R", [(32, 64, 2, 16, 16, 7), (64, 128, 2, 128, 128, 5), (16, 40, 1, 8, 24, 3),
                                                   (16, 32, 0, 8, 8, 4), (32, 64, 3, 20, 20, 1), (64, 128, 2, 20, 20, 187),
-                                                  (32, 64, 2, 16, 16, 600)])
-def test_weight_generator_backward_matches_autograd_of_the_oracle(T, Hh, nh, d_in, d_out, R):
+                                                  (32, 64, 2, 16, 16, 600), (64, 256, 2, 64, 64, 70), (300, 48, 1, 8, 8, 3)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_weight_generator_backward_matches_autograd_of_the_oracle(T, Hh, nh, d_in, d_out, R, fused, monkeypatch):
     """Reference tests/test_weight_generator.py:86-106 (gradient reaches the embedding, the scales train) made exact: every
-    gradient of WeightGenerator.forward against torch.autograd through the oracle, in float64."""
+    gradient of WeightGenerator.forward against torch.autograd through the oracle, in float64 — through ghf_weightgen_bwd (all
+    heads and layers in three launches; widths up to 256) and through the per-operation chain it replaces."""
+    from graph_hypernetwork_forge_amd import autograd as A
+    monkeypatch.setattr(A, "_WG_FUSED_BWD", 2 if fused else 0)
+    calls = []
+    real = _native.weightgen_bwd
+    monkeypatch.setattr(_native, "weightgen_bwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     torch.manual_seed(T + Hh + nh)
     gen = WeightGenerator(T, d_in, d_out, hidden_dim=Hh, num_hidden=nh).to(DEV)
     with torch.no_grad():
@@ -835,6 +842,7 @@ def test_weight_generator_backward_matches_autograd_of_the_oracle(T, Hh, nh, d_i
     out = gen(x)
     gouts = {k: torch.from_numpy(synth.normal(6, "g" + k, tuple(v.shape))) for k, v in out.items()}
     sum((out[k] * gouts[k].to(DEV)).sum() for k in out).backward()
+    assert len(calls) == (1 if fused and max(T, Hh if nh else 0) <= 256 else 0)
     ref_p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in gen.state_dict(keep_vars=True).items()}
     xr = x.detach().cpu().double().requires_grad_(True)
     ref = O.weight_generator(ref_p, "", xr, d_in, d_out, dtype=torch.float64)
