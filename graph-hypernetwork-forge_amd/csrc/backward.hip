@@ -596,6 +596,9 @@ __global__ __launch_bounds__(256) void rowscale_absmax_kernel(const float* __res
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + blockIdx.y, __float_as_uint(m));
 }
 
+#ifndef GHF_EO_SRC_LAST
+#define GHF_EO_SRC_LAST 1
+#endif
 #ifndef GHF_EO_STAGES_A
 #define GHF_EO_STAGES_A 2  // register sets of gathered SOURCE rows in flight in edge_outer_h_kernel (2 or 3)
 #endif
@@ -715,7 +718,13 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
     // requested in): row-major images.  Rows past the slice's end (copies of its last edge's rows) are cut as zeros by a zero
     // scale (a copy of a row the sums hold anyway: 0 x inf could only put a NaN where the result is no number already).
     auto commit_unit = [&](int buf, int k, int unit, int tile) __attribute__((always_inline)) {   // tile's rows: sa[k % NSA], sb[k % NSB], k = tile mod TRIP
+#if GHF_EO_SRC_LAST
+        // units in the order the rows were requested in: the destination rows of h and G first, the source rows — the ones that
+        // come from HBM rather than the Infinity Cache — last: half a step more for them to arrive
+        const int j = unit < 2 * LPR ? unit / 2 : unit - 2 * LPR, reg = unit < 2 * LPR ? 1 + unit % 2 : 0;
+#else
         const int j = unit / 3, reg = unit % 3;
+#endif
         char* base = eoh_lds + (size_t)buf * 6 * IMG;
         const int row = (t + NT * j) / F4, c4 = (t + NT * j) % F4;
         const unsigned o = eo_off(row, c4 >> 1) + 8u * (c4 & 1);
@@ -776,8 +785,13 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
         constexpr int K = decltype(K_)::value;
         load_idx_a(tile + NSA + 1, ixa[(K + NSA + 1) & 1]);
         load_idx_b(tile + NSB + 1, ixb[(K + NSB + 1) & 1]);
+#if GHF_EO_SRC_LAST
+        gather_b(sb[K % NSB], ixb[(K + NSB) & 1]);
+        gather_a(sa[K % NSA], ixa[(K + NSA) & 1]);
+#else
         gather_a(sa[K % NSA], ixa[(K + NSA) & 1]);
         gather_b(sb[K % NSB], ixb[(K + NSB) & 1]);
+#endif
         __builtin_amdgcn_sched_barrier(0);                // (the loads stay at the top of the step: left alone hipcc sinks them to its end)
         const char* base = eoh_lds + (size_t)(K & 1) * 6 * IMG;
         const char* ximg = base + (rg >> 1) * 2 * IMG;    // rows 0..127 of [X_src | X_dst] are the source image, 128..255 the destination one
