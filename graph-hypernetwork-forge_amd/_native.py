@@ -660,6 +660,8 @@ def edge_outer(h: torch.Tensor, G: torch.Tensor, src: torch.Tensor, dst: torch.T
             raise ValueError("edge_outer: one row scale per row of h and of G expected")
         _check(lib.ghf_edge_outer_scaled(_ptr(h), _ptr(G), _ptr(hsc), _ptr(gsc), *tabs, ns, R, d, h.size(0), _ptr(ws), _ptr(dW),
                                          _ptr(db), _stream()), "ghf_edge_outer_scaled")
+        if os.environ.get("GHF_EO_GUARD_DEBUG"):             # (diagnostics: the range guard's counters of this call, ghf.h)
+            print("edge_outer guard (far-down rows, nonzero rows) of h, G:", ws[ns * (2 * D * D + D) + 2:].view(torch.int32)[:4].tolist(), flush=True)
     else:
         _check(lib.ghf_edge_outer(_ptr(h), _ptr(G), *tabs, ns, R, d, 0 if exact else h.size(0), _ptr(ws), _ptr(dW), _ptr(db),
                                   _stream()), "ghf_edge_outer")

@@ -391,17 +391,48 @@ __global__ __launch_bounds__(256) void group_outer_kernel(const float* __restric
 // product in accumulators: wave (rg, cg) owns 64 x 64 of it as 4 x 4 tiles of v_mfma_f32_16x16x4_f32 whose operands are
 // single ds_read_b128 per k-step (lane (i, k) reads columns 4i..4i+3 of row k: register a feeds the tile of rows
 // {4i + a}).  Exact fp32; partial products are summed per relation in slice order by edge_outer_reduce_kernel.
+// Range guard of the one-scale-per-tensor pieces (ghf.h: ghf_edge_outer_scaled).  A row whose largest magnitude lies 2^-15
+// or more below the tensor's sits, after the tensor's scale, below 0.5 throughout — the two fp16 pieces then keep fewer
+// than 22 bits of it (common.h: range_tiny).  That alone is harmless and common: a training step's G has 27 - 47 % such rows
+// at BASELINE config 3 (the nodes the loss does not touch: their gradient arrives through two layers of 0.01-scale weights), and
+// what they add to a relation's sum is 2^-15 of what its other rows add.  It matters when the rows that SET the scale are
+// few — an outlier row 2^20 above everything else leaves every relation that does not touch it a sum of far-down rows only.
+// cnt[2 y] += far-down rows of tensor y, cnt[2 y + 1] += its nonzero rows; the contraction kernels read the four counters:
+// eo_wide() — at least 7/8 of either tensor's nonzero rows that far down — sends the call to the exact fp32 chain.  (Row scales
+// are 2^-s(row), s = split2h_shift(the row's largest magnitude); a zero row's shift is the clamp, 100.)
+__global__ __launch_bounds__(256) void rowscale_guard_kernel(const float* __restrict__ s0, const float* __restrict__ s1, int64_t n,
+                                                             const unsigned* __restrict__ amax, int* __restrict__ cnt) {
+    const float* __restrict__ sc = blockIdx.y ? s1 : s0;
+    const int st = split2h_shift(__uint_as_float(amax[blockIdx.y]));
+    int tiny = 0, nz = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int sr = 127 - (int)((__float_as_uint(sc[i]) >> 23) & 255);       // the row's shift
+        if (sr < 100) {
+            ++nz;
+            tiny += sr - st >= 15;
+        }
+    }
+    tiny = (int)wave_sum((float)tiny);
+    nz = (int)wave_sum((float)nz);
+    if ((threadIdx.x & 63) == 0 && nz) {
+        if (tiny) atomicAdd(cnt + 2 * blockIdx.y, tiny);
+        atomicAdd(cnt + 2 * blockIdx.y + 1, nz);
+    }
+}
+__device__ __forceinline__ bool eo_wide(const int* __restrict__ cnt) {
+    return cnt && ((cnt[0] > 0 && (int64_t)cnt[0] * 8 >= (int64_t)cnt[1] * 7) || (cnt[2] > 0 && (int64_t)cnt[2] * 8 >= (int64_t)cnt[3] * 7));
+}
+
 constexpr int EO_ET = 32;                                 // edges per tile
 
 template <int D>
 // Wider rows (d % 128 == 0) run the D = 128 instance once per [256, 128] tile of the [2d, d] gradient: ia / ib name the
 // rows (sources or destinations) and xa_col / xb_col the two 128-column pieces of them that make the tile's 256 rows, g_col
 // the tile's 128 columns of G (always indexed by destination), ld = d the row stride of h and G.
-__global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kernel(
+__device__ __forceinline__ void edge_outer_slice(
     const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
     const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
-    const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b,
-    const int32_t* __restrict__ order) {
+    const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b, const size_t slice) {
     constexpr int RG = 2 * D / 64, CG = D / 64, NT = RG * CG * 64;
     constexpr int F4 = D / 4;                             // float4 per row of h / G
     constexpr int LPR = EO_ET * F4 / NT;                  // rows x float4 each thread moves per region and tile
@@ -413,7 +444,6 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int rg = w / CG, cg = w % CG;
     const int c16 = lane & 15, q = lane >> 4;
-    const size_t slice = order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x;
     const int64_t e0 = slice_tab[3 * slice + 1], e1 = slice_tab[3 * slice + 2];
     const int ntiles = (int)((e1 - e0 + EO_ET - 1) / EO_ET);
 
@@ -511,6 +541,32 @@ __global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kerne
     }
 }
 
+template <int D>
+__global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_kernel(
+    const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+    const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
+    const int64_t* __restrict__ slice_tab, float* __restrict__ partial, float* __restrict__ partial_b,
+    const int32_t* __restrict__ order) {
+    edge_outer_slice<D>(h, G, ia, ib, dst, xa_col, xb_col, g_col, ld, slice_tab, partial, partial_b,
+                        order ? (size_t)order[blockIdx.x] : (size_t)blockIdx.x);
+}
+
+// The range guard's fallback (ghf.h: ghf_edge_outer_scaled): the same slices on the exact chain when eo_wide(guard) says so —
+// a small grid whose workgroups walk the slices, so that the launch costs next to nothing in the usual case (every workgroup
+// returns at once) instead of dispatching one 98 KB workgroup per slice to do so.
+template <int D>
+__global__ __launch_bounds__((2 * D / 64) * (D / 64) * 64) void edge_outer_guarded_kernel(
+    const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+    const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
+    const int64_t* __restrict__ slice_tab, int64_t nslices, float* __restrict__ partial, float* __restrict__ partial_b,
+    const int* __restrict__ guard) {
+    if (!eo_wide(guard)) return;
+    for (int64_t slice = blockIdx.x; slice < nslices; slice += gridDim.x) {
+        edge_outer_slice<D>(h, G, ia, ib, dst, xa_col, xb_col, g_col, ld, slice_tab, partial, partial_b, (size_t)slice);
+        __syncthreads();
+    }
+}
+
 // dW[r] tile = sum of its slices' partial products in slice order (x: float4 of the [2D, D] tile, y: relation); db likewise.
 // The tile sits at (row0, col0) of the relation's [2d, d] matrix (row0 = col0 = 0, D = d for the single-tile sizes).
 __global__ __launch_bounds__(256) void edge_outer_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
@@ -535,7 +591,16 @@ __global__ __launch_bounds__(256) void edge_outer_reduce_kernel(const float* __r
 template <int D>
 static int edge_outer_launch(const float* h, const float* G, const int64_t* ia, const int64_t* ib, const int64_t* dst, int xa_col,
                              int xb_col, int g_col, int ld, const int64_t* slice_tab, int64_t nslices, float* partial,
-                             float* partial_b, const int32_t* order, hipStream_t stream) {
+                             float* partial_b, const int32_t* order, hipStream_t stream, const int* guard = nullptr) {
+    if (guard) {
+        constexpr int NTG = (2 * D / 64) * (D / 64) * 64;
+        const size_t ldsg = (size_t)2 * EO_ET * 3 * D * sizeof(float);
+        GHF_SET_MAX_LDS(edge_outer_guarded_kernel<D>, ldsg);
+        edge_outer_guarded_kernel<D><<<(unsigned)(nslices < 256 ? nslices : 256), NTG, ldsg, stream>>>(h, G, ia, ib, dst, xa_col, xb_col, g_col, ld,
+                                                                                                       slice_tab, nslices, partial, partial_b, guard);
+        GHF_LAUNCH_CHECK();
+        return GHF_OK;
+    }
     constexpr int NT = (2 * D / 64) * (D / 64) * 64;
     const size_t lds = (size_t)2 * EO_ET * 3 * D * sizeof(float);
     GHF_SET_MAX_LDS(edge_outer_kernel<D>, lds);
@@ -616,8 +681,10 @@ __global__ __launch_bounds__(512) void edge_outer_h_kernel(
     const float* __restrict__ h, const float* __restrict__ G, const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
     const int64_t* __restrict__ dst, int xa_col, int xb_col, int g_col, int ld,
     const int64_t* __restrict__ slice_tab, const unsigned* __restrict__ amax /* bits of max|h|, max|G| */,
-    float* __restrict__ partial, float* __restrict__ partial_b, const int32_t* __restrict__ order) {
+    float* __restrict__ partial, float* __restrict__ partial_b, const int32_t* __restrict__ order,
+    const int* __restrict__ guard /* rowscale_guard_kernel's counters, or NULL */) {
     constexpr int D = 128, RG = 4, CG = 2, NT = 512;
+    if (eo_wide(guard)) return;                           // (the exact kernel, launched behind this one, takes the call)
     constexpr int F4 = D / 4;                             // float4 per row of h / G
     constexpr int LPR = EO_ET * F4 / NT;                  // (row, float4) items each thread moves per region and tile: 2
     constexpr int IMG = EO_ET * 256;                      // bytes of one [32][128] fp16 image
@@ -888,11 +955,19 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
     static const bool exact = getenv("GHF_EDGE_OUTER") && !strcmp(getenv("GHF_EDGE_OUTER"), "exact");
     unsigned* amax = (unsigned*)(partial_b + (size_t)nslices * D);     // two words behind the partial sums: max |h|, max |G|
     const bool pieces = D == 128 && !exact && N > 0;      // (N <= 0: the caller asks for the exact fp32 chain, ghf.h)
+    int* guard = nullptr;                                  // four counters behind the two maxima (ghf.h: the workspace's last 64 floats)
     if (pieces) {
-        GHF_HIP_CHECK(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), stream));
+        GHF_HIP_CHECK(hipMemsetAsync(amax, 0, 6 * sizeof(unsigned), stream));
         if (h_rowscale && G_rowscale) {                    // the caller holds both tensors' split forms: their row scales say it
-            const unsigned ag = (unsigned)(cdiv(N, 256 * 4) < 1024 ? cdiv(N, 256 * 4) : 1024);
+            // (few workgroups: every wave ends in atomics on the same two — six — words, which serialise in L2: 1,000
+            // workgroups of them cost ~0.1 ms per call at N = 10^6, 128 next to nothing; the scales are 4 MB per tensor)
+            const unsigned ag = (unsigned)(cdiv(N, 256 * 4) < 128 ? cdiv(N, 256 * 4) : 128);
             rowscale_absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h_rowscale, G_rowscale, N, amax);
+            static const bool guarded = !(getenv("GHF_EO_GUARD") && !strcmp(getenv("GHF_EO_GUARD"), "0"));
+            if (guarded) {
+                guard = (int*)(amax + 2);
+                rowscale_guard_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h_rowscale, G_rowscale, N, amax, guard);
+            }
         } else {
             const unsigned ag = (unsigned)(cdiv(N * d, 256 * 16) < 2048 ? cdiv(N * d, 256 * 16) : 2048);
             absmax_kernel<<<dim3(ag, 2), 256, 0, stream>>>(h, G, N * d, amax);
@@ -910,13 +985,17 @@ int launch_edge_outer(const float* h, const float* G, const int64_t* src, const 
                 if ((uint64_t)N * (uint64_t)d * 4u < (1ull << 32)) {
                     GHF_SET_MAX_LDS(edge_outer_h_kernel<true>, lds);
                     edge_outer_h_kernel<true><<<(unsigned)nslices, 512, lds, stream>>>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab,
-                                                                                       amax, partial, partial_b, order);
+                                                                                       amax, partial, partial_b, order, guard);
                 } else {
                     GHF_SET_MAX_LDS(edge_outer_h_kernel<false>, lds);
                     edge_outer_h_kernel<false><<<(unsigned)nslices, 512, lds, stream>>>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab,
-                                                                                        amax, partial, partial_b, order);
+                                                                                        amax, partial, partial_b, order, guard);
                 }
                 GHF_LAUNCH_CHECK();
+                // the same slices on the exact fp32 chain, behind it: every workgroup of one of the two returns at once, which
+                // one the counters say — no host round trip
+                if (guard) rc = edge_outer_launch<128>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial, partial_b,
+                                                       order, stream, guard);
             } else
                 rc = D == 128 ? edge_outer_launch<128>(h, G, ia, ib, dst, fa % d, fb % d, cb * D, d, slice_tab, nslices, partial,
                                                        partial_b, order, stream)

@@ -326,7 +326,15 @@ int ghf_edge_outer(const float* h, const float* G, const int64_t* src, const int
 /* The same for a caller that holds the split forms of h and G (ghf_split_rows / the h_split_out of a layer / ghf_tail_bwd's
  * G_split): h_rowscale, G_rowscale [N] = their row scales (the N floats behind the N split rows).  The one scale per tensor is
  * then read off those (2^13 max_row 2^-s(row) has the exponent of the tensor's largest magnitude) instead of by a pass over
- * both tensors: same pieces, same products, same bits as ghf_edge_outer with N > 0.  N > 0 required. */
+ * both tensors: same pieces, same products, same bits as ghf_edge_outer with N > 0.  N > 0 required.
+ * Range guard (round 4): the row scales also say how many NONZERO rows of a tensor lie 2^-15 or more below its largest
+ * magnitude — rows the one scale leaves below 0.5, where two fp16 pieces keep fewer than 22 bits.  Some such rows are normal
+ * (a training step's G: the nodes the loss does not touch) and add 2^-15 of what the others add; when they are at least 7/8
+ * of either tensor's nonzero rows — a few outlier rows set the scale and the bulk of the tensor would be cut short — the call
+ * runs on the exact fp32 chain instead (the bits of N <= 0), decided on the device: both kernels are enqueued and the
+ * workgroups of one return at once.  GHF_EO_GUARD=0 in the environment removes it.  The four counters (far-down rows, nonzero
+ * rows; of h, of G) stay in the workspace behind the partial sums and the two maxima:
+ * ints at float offset nslices * (2*D*D + D) + 2. */
 int ghf_edge_outer_scaled(const float* h, const float* G, const float* h_rowscale, const float* G_rowscale, const int64_t* src,
                           const int64_t* dst, const int64_t* slice_tab, const int64_t* slice_off, const int32_t* order,
                           int64_t nslices, int R, int d, int64_t N, float* workspace, float* dW, float* db, void* stream);

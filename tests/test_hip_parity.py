@@ -758,15 +758,38 @@ def test_edge_outer_matches_the_plain_contraction(d, N, E, R):
             assert torch.equal(base[0], perm[0]) and torch.equal(base[1], perm[1])
     if d % 128 == 0:
         # ghf_edge_outer_scaled: the one scale per tensor read off the row scales of the split forms — the same bits
-        # (rows scaled apart by 2^20 and a row of zeros: the tensor's scale is its largest row's)
-        h2 = h.copy()
-        h2[3] *= 2.0 ** 20
-        h2[5] = 0.0
-        hs, gs = _native.split_rows(t(h2), _native.WLAYOUT_SPLIT2H), _native.split_rows(t(G), _native.WLAYOUT_SPLIT2H)
-        plain = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
-        scaled = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R,
-                                    h_scales=_native.split_row_scales(hs, N, d), G_scales=_native.split_row_scales(gs, N, d))
-        assert torch.equal(plain[0], scaled[0]) and torch.equal(plain[1], scaled[1])
+        # (rows scaled apart by 2^10 and a row of zeros: the tensor's scale is its largest row's; apart by 2^20 — one outlier row
+        # sets the scale for all the others — the scaled call's range guard sends it to the exact chain, see below)
+        for lift, same in ((10, True), (20, False)):
+            h2 = h.copy()
+            h2[3] *= 2.0 ** lift
+            h2[5] = 0.0
+            hs, gs = _native.split_rows(t(h2), _native.WLAYOUT_SPLIT2H), _native.split_rows(t(G), _native.WLAYOUT_SPLIT2H)
+            plain = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
+            scaled = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R,
+                                        h_scales=_native.split_row_scales(hs, N, d), G_scales=_native.split_row_scales(gs, N, d))
+            if not same:
+                plain = _native.edge_outer(t(h2), t(G), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R, exact=True)
+            assert torch.equal(plain[0], scaled[0]) and torch.equal(plain[1], scaled[1]), f"lift 2^{lift}"
+        # the range guard of the one-scale pieces (ghf.h): fifteen rows in sixteen of G 2^-20 below the rest (a few rows set the
+        # scale) — the call runs on the exact fp32 chain, decided on the device; a quarter of the rows that far down (what a
+        # training step's G looks like) does not trip it
+        hs1 = _native.split_rows(t(h), _native.WLAYOUT_SPLIT2H)
+        for keep_every, trips in ((16, True), (0, False)):
+            G3 = G.copy()
+            if keep_every:
+                small = np.arange(N) % keep_every != 0
+            else:
+                small = np.arange(N) % 4 == 0
+            G3[small] *= 2.0 ** -20
+            gs3 = _native.split_rows(t(G3), _native.WLAYOUT_SPLIT2H)
+            kw = dict(h_scales=_native.split_row_scales(hs1, N, d), G_scales=_native.split_row_scales(gs3, N, d))
+            got = _native.edge_outer(t(h), t(G3), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R, **kw)
+            exact_chain = _native.edge_outer(t(h), t(G3), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R, exact=True)
+            pieces = _native.edge_outer(t(h), t(G3), tp.src_by_rel, tp.dst_by_rel, tp.slice_tab, tp.slice_off, R)
+            want = exact_chain if trips else pieces
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), f"guard {'did not trip' if trips else 'tripped'}"
+            assert not torch.equal(exact_chain[0], pieces[0]) or N < 100      # (the two chains do differ in their last bits)
     h64, G64 = h.astype(np.float64), G.astype(np.float64)
     for r in range(R):
         m = rel == r
