@@ -49,6 +49,9 @@ if _i:
 _e = _re.search(r"eoNS(\d)(\d)", VARIANT)
 if _e:                                                   # backward.hip: edge_outer_h's register sets of source / destination rows in flight
     FLAGS += ["-DGHF_EO_STAGES_A=" + _e.group(1), "-DGHF_EO_STAGES_B=" + _e.group(2)]
+_e = _re.search(r"wgHU(\d+)", VARIANT)
+if _e:
+    FLAGS.append("-DGHF_WG_HU=" + _e.group(1))          # weightgen.hip: output units per wave and batch of wg_hidden_kernel
 _e = _re.search(r"eoSRCLAST(\d)", VARIANT)
 if _e:
     FLAGS.append("-DGHF_EO_SRC_LAST=" + _e.group(1))    # backward.hip: edge_outer_h's source rows requested and cut last

@@ -20,6 +20,10 @@ namespace ghf {
 
 constexpr int WG_MAX_WIDTH = 1024;   // max(T, Hh) supported by the LDS ping-pong buffers
 constexpr int WG_UNROLL = 8;         // independent dot products per wave and step in the latency-bound small kernels
+#ifndef GHF_WG_HU
+#define GHF_WG_HU 32
+#endif
+constexpr int WG_HU = GHF_WG_HU;     // ... of wg_hidden_kernel: a wave's whole share of a 128-unit layer in one batch of loads
 
 struct HeadPtrs {
     const float* w[3][8];     // [head][layer] weight
@@ -46,20 +50,20 @@ __global__ __launch_bounds__(256) void wg_hidden_kernel(const float* __restrict_
     for (int li = 0; li < num_hidden; ++li) {
         const float* __restrict__ W = P.w[head][li];
         const float* __restrict__ B = P.b[head][li];
-        // one wave per output unit: lanes stride the contraction, then a wave reduction; WG_UNROLL units at a time so
+        // one wave per output unit: lanes stride the contraction, then a wave reduction; WG_HU units at a time so
         // that their weight loads are in flight together (one at a time this kernel was 64 serial L2 latencies long)
-        for (int j0 = wv * WG_UNROLL; j0 < Hh; j0 += nw * WG_UNROLL) {
-            float s[WG_UNROLL];
+        for (int j0 = wv * WG_HU; j0 < Hh; j0 += nw * WG_HU) {
+            float s[WG_HU];
 #pragma unroll
-            for (int u = 0; u < WG_UNROLL; ++u) s[u] = 0.f;
+            for (int u = 0; u < WG_HU; ++u) s[u] = 0.f;
             for (int k = lane; k < in_dim; k += 64) {
                 const float xk = buf[cur][k];
 #pragma unroll
-                for (int u = 0; u < WG_UNROLL; ++u)
+                for (int u = 0; u < WG_HU; ++u)
                     if (j0 + u < Hh) s[u] = fmaf(xk, W[(size_t)(j0 + u) * in_dim + k], s[u]);
             }
 #pragma unroll
-            for (int u = 0; u < WG_UNROLL; ++u) {
+            for (int u = 0; u < WG_HU; ++u) {
                 const float t = wave_sum(s[u]);
                 if (lane == 0 && j0 + u < Hh) {             // Linear -> ReLU -> Dropout (reference weight_generator.py:96-107)
                     const float a = fmaxf(t + B[j0 + u], 0.f);
