@@ -135,7 +135,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // tile's rows are gathered once per 256 columns instead of once per 128: at d = 256 every gathered row is fetched once, not
 // twice (BASELINE config 5: 91 GB of 205 GB per layer were pass 1's fetches, profiles/r02_c5_kernel_pmc.json).
 #ifndef GHF_RSEXP
-#define GHF_RSEXP 0          // timing-only ablations of pass 1 (wrong results): 1 no MFMAs, 2 no global fetches, 4 no commits to LDS, 16 every gathered row one of 64 (L2-resident)
+#define GHF_RSEXP 0          // timing-only ablations of pass 1 (wrong results): 1 no MFMAs, 2 no global fetches, 4 no commits to LDS, 8 no fragment reads, 16 every gathered row one of 64 (L2-resident), 32 no barrier per step, 64 no result rows written
 #endif
 template <int KH, int NCT>
 __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_kernel(
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
                 f32x4 o;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) o[s] = fmaf(acc[rt][ct][s], fv, bv[ct][s] * n);
-                *(f32x4*)(y + 16 * ct) = o;
+                if (!(GHF_RSEXP & 64) || o[0] == 123.456f) *(f32x4*)(y + 16 * ct) = o;   // (64, timing: no result rows written)
             }
         }
     }
@@ -340,6 +340,13 @@ __global__ __launch_bounds__(256 * NCT, KH == 32 ? 2 : 1) void edge_transform_h_
 // Measured (one GPU's share of C5, 27,118 tiles; tools/c5_shard_check.py under rocprofv3): 4.37 -> 3.95 ms per launch, the whole
 // C5 layer 41.3 -> 38.8 ms.  Ablations of THIS kernel (GHF_VARIANT=rsexp<mask>): without MFMAs 3.14, without the gathers 2.60,
 // with every gathered row one of 64 L2-resident rows 3.21 — its matrix work alone is 1.09 ms at the dense fp16 peak.  What is left
+// (Second set, another box, 3.80 ms: no fragment reads 3.34, no barrier 3.68, no result rows 3.77, neither MFMAs nor fragment
+// reads 3.11 — a kernel that only moves its tiles into LDS still takes 82 % of the time.  The ring is a FIFO (loads return in
+// order): two steps = 96 KB in flight per CU against a loaded round trip of ~3 us for the gathered rows' 64-byte pieces is
+// 5.5 TB/s of tile traffic, what the kernel runs at.  More in flight needs more LDS than there is: the weights' tile is two
+// thirds of a step's bytes and must be there for all four row groups; a deeper ring for the rows alone does not help, because
+// a weight tile requested later with an earlier deadline waits in line behind the rows requested before it.)
+// What is left
 // is per work item: the descriptor chain in front of the first tile (slice entry -> row ids -> rows: ~5 us of ~37 us, nothing else
 // runs on the CU meanwhile at one 149 KB workgroup per CU) and row latency at two steps of lookahead.  Tried and NOT kept: a
 // persistent form (one workgroup per CU walking the items, rows three / weights two steps ahead in 4 + 3 buffers = all 160 KiB,
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void edge_transform_h3_kernel(
     }
     i32x4 a[2][2], b0[4][2], b1[4][2];
     auto read_a = [&](unsigned buf) {
+        if (GHF_RSEXP & 8) return;                         // (timing: no fragment reads)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const unsigned ad = lds0 + buf + aoff[rt];
@@ -430,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void edge_transform_h3_kernel(
         }
     };
     auto read_b = [&](unsigned buf, int ch, i32x4 (&b)[4][2]) {
+        if (GHF_RSEXP & 8) return;
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             const unsigned ad = lds0 + buf + boff[4 * ch + c4];
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void edge_transform_h3_kernel(
         // done; behind the barrier that holds for every wave
         asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]),
                      "+v"(b1[2][0]), "+v"(b1[2][1]), "+v"(b1[3][0]), "+v"(b1[3][1]) :: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(GHF_RSEXP & 32)) __builtin_amdgcn_s_barrier();   // (32, timing: no barrier per step)
         i32x4 a_keep[2][2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
