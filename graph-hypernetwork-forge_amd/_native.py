@@ -47,7 +47,7 @@ SIGNATURES = {
     "ghf_plan_build": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp]),
     "ghf_weightgen_fwd": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
-                                 _vp, _vp, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp]),
     "ghf_weightgen_fwd_batched": (_i32, [_i32, _vp, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                          C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "ghf_input_proj_fwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -310,10 +310,11 @@ def plan_build(edge_index: torch.Tensor, rel_id: torch.Tensor, N: int, R: int, b
 def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], log_scales: Sequence[torch.Tensor],
                   T: int, Hh: int, num_hidden: int, d_in: int, d_out: int, layout: int,
                   out: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], torch.Tensor]] = None,
-                  hidden_drop: Optional[torch.Tensor] = None):
+                  hidden_drop: Optional[torch.Tensor] = None, want_acts: bool = False):
     """head_params: flat list [head][layer][weight,bias]; log_scales: the three 1-element tensors (W_msg, W_self, bias),
     read in place; hidden_drop: scaled dropout masks [3, num_hidden, R, Hh] of the hidden activations (training);
-    returns (W_msg or Wfrag, W_self or None, bias)."""
+    returns (W_msg or Wfrag, W_self or None, bias) — and, with want_acts, a fourth entry: the hidden activations
+    [3, num_hidden, R, Hh] the same launch leaves for the backward (weightgen_acts' result; None without hidden layers)."""
     lib = load()
     x = _req(text_emb, torch.float32, "text_emb")
     R = x.size(0)
@@ -337,11 +338,12 @@ def weightgen_fwd(text_emb: torch.Tensor, head_params: Sequence[torch.Tensor], l
         bias = torch.empty(R, d_out, dtype=torch.float32, device=dev)
     else:
         W_msg, W_self, bias = out
+    acts = torch.empty(3, num_hidden, R, Hh, dtype=torch.float32, device=dev) if want_acts and num_hidden > 0 else None
     _check(lib.ghf_weightgen_fwd(_ptr(x), arr, ls, R, T, Hh, num_hidden, d_in, d_out, layout,
                                  _ptr(hidden_ws), _ptr(W_msg), _ptr(W_self), _ptr(bias),
-                                 _ptr(None if hidden_drop is None else _req(hidden_drop, torch.float32, "hidden_drop")), _stream()),
-           "ghf_weightgen_fwd")
-    return W_msg, W_self, bias
+                                 _ptr(None if hidden_drop is None else _req(hidden_drop, torch.float32, "hidden_drop")), _ptr(acts),
+                                 _stream()), "ghf_weightgen_fwd")
+    return (W_msg, W_self, bias, acts) if want_acts else (W_msg, W_self, bias)
 
 
 def weightgen_fwd_batched(text_emb: torch.Tensor, head_params: Sequence[Sequence[torch.Tensor]], log_scales: Sequence[Sequence[torch.Tensor]],

@@ -276,8 +276,10 @@ class WeightGeneratorFn(torch.autograd.Function):
         x = x.contiguous().float()
         flat = [p.detach() for p in params]
         ls = torch.cat([ls0.detach().reshape(1), ls1.detach().reshape(1), ls2.detach().reshape(1)])
-        outs = _native.weightgen_fwd(x, flat, ls, T, Hh, nh, d_in, d_out, _native.WLAYOUT_NATURAL, hidden_drop=hidden_drop)
-        acts = _native.weightgen_acts(x, flat, T, Hh, nh, hidden_drop=hidden_drop) if nh > 0 else None
+        # (the hidden activations the backward needs leave with the same launch)
+        *outs, acts = _native.weightgen_fwd(x, flat, ls, T, Hh, nh, d_in, d_out, _native.WLAYOUT_NATURAL, hidden_drop=hidden_drop,
+                                            want_acts=True)
+        outs = tuple(outs)
         ctx.dims, ctx.acts, ctx.n_params, ctx.log_keep = dims[:5], acts, len(params), log_keep
         ctx.save_for_backward(x, ls, *outs, *params)
         return outs

@@ -121,11 +121,11 @@ int ghf_plan_build(const int64_t* edge_index, const int64_t* rel_id, int64_t N, 
 
 int ghf_weightgen_fwd(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                       int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout, float* hidden_ws,
-                      float* W_msg, float* W_self, float* bias, const float* hidden_drop, void* stream) {
+                      float* W_msg, float* W_self, float* bias, const float* hidden_drop, float* acts, void* stream) {
     GHF_REQUIRE(text_emb && head_params && log_scales && log_scales[0] && log_scales[1] && log_scales[2] && hidden_ws && W_msg && bias,
                 "weightgen_fwd: null pointer argument");
     return launch_weightgen(text_emb, head_params, log_scales, R, T, Hh, num_hidden, d_in, d_out, layout,
-                            hidden_ws, W_msg, W_self, bias, hidden_drop, (hipStream_t)stream);
+                            hidden_ws, W_msg, W_self, bias, hidden_drop, (hipStream_t)stream, acts);
 }
 
 int ghf_weightgen_fwd_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,

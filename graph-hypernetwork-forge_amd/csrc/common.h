@@ -153,11 +153,12 @@ constexpr int32_t SRC_MASK = (1 << SRC_BITS) - 1;
 
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
-                     float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream);
+                     float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream,
+                     float* acts = nullptr);
 int launch_weightgen_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,
                              int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                              float* hidden_ws, float* const* W_msg, float* const* W_self, float* const* bias,
-                             const float* hidden_drop, hipStream_t stream);
+                             const float* hidden_drop, hipStream_t stream, float* acts = nullptr);
 
 int launch_rows_pack(bool unpack, void* rows, int64_t row_bytes, void* extra, int64_t extra_bytes, const int64_t* idx, int64_t n,
                      int64_t nrows, void* packed, hipStream_t stream);

@@ -404,14 +404,14 @@ int launch_weights_pack(const float* top, const float* bottom, int transpose, in
 int launch_weightgen_batched(int L, const float* text_emb, const float* const* head_params, const float* const* log_scales,
                              int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
                              float* hidden_ws, float* const* W_msg, float* const* W_self, float* const* bias,
-                             const float* hidden_drop, hipStream_t stream) {
+                             const float* hidden_drop, hipStream_t stream, float* acts) {
     GHF_REQUIRE(L >= 1 && L <= WG_MAX_L, "weightgen: %d generators per call (1..%d)", L, WG_MAX_L);
     GHF_REQUIRE(R > 0 && T > 0 && d_in > 0 && d_out > 0, "weightgen: R, T, d_in, d_out must be positive");
     GHF_REQUIRE(num_hidden >= 0 && num_hidden <= 7, "weightgen: num_hidden=%d outside [0,7]", num_hidden);
     GHF_REQUIRE(num_hidden == 0 || Hh > 0, "weightgen: hidden_dim must be positive");
     GHF_REQUIRE(T <= WG_MAX_WIDTH && Hh <= WG_MAX_WIDTH, "weightgen: text_dim/hidden_dim > %d unsupported", WG_MAX_WIDTH);
     GHF_REQUIRE(layout == GHF_WLAYOUT_NATURAL || layout == GHF_WLAYOUT_FRAG16 || layout == GHF_WLAYOUT_SPLIT2H, "weightgen: bad layout %d", layout);
-    GHF_REQUIRE(!hidden_drop || L == 1, "weightgen: dropout masks go with one generator per call");
+    GHF_REQUIRE((!hidden_drop && !acts) || L == 1, "weightgen: dropout masks / saved activations go with one generator per call");
     for (int g = 0; g < L; ++g) {
         GHF_REQUIRE(W_msg[g] && bias[g], "weightgen: null output pointer (generator %d)", g);
         if (layout == GHF_WLAYOUT_SPLIT2H)
@@ -432,7 +432,7 @@ int launch_weightgen_batched(int L, const float* text_emb, const float* const* h
                 PL.p[g].b[h][l] = head_params[((size_t)(g * 3 + h) * nl + l) * 2 + 1];
                 GHF_REQUIRE(PL.p[g].w[h][l] && PL.p[g].b[h][l], "weightgen: null parameter pointer (generator %d head %d layer %d)", g, h, l);
             }
-    wg_hidden_kernel<<<dim3(R, 3, L), 256, 0, stream>>>(text_emb, PL, R, T, Hh, num_hidden, hidden_ws, nullptr, hidden_drop);
+    wg_hidden_kernel<<<dim3(R, 3, L), 256, 0, stream>>>(text_emb, PL, R, T, Hh, num_hidden, hidden_ws, acts, hidden_drop);
     GHF_LAUNCH_CHECK();
 
     const int Hl = num_hidden ? Hh : T;
@@ -503,12 +503,13 @@ int launch_weightgen_batched(int L, const float* text_emb, const float* const* h
 
 int launch_weightgen(const float* text_emb, const float* const* head_params, const float* const* log_scales,
                      int R, int T, int Hh, int num_hidden, int d_in, int d_out, int layout,
-                     float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream) {
+                     float* hidden_ws, float* W_msg, float* W_self, float* bias, const float* hidden_drop, hipStream_t stream,
+                     float* acts) {
     float* wm[1] = {W_msg};
     float* wsf[1] = {W_self};
     float* bs[1] = {bias};
     return launch_weightgen_batched(1, text_emb, head_params, log_scales, R, T, Hh, num_hidden, d_in, d_out, layout, hidden_ws,
-                                    wm, wsf, bs, hidden_drop, stream);
+                                    wm, wsf, bs, hidden_drop, stream, acts);
 }
 
 }  // namespace ghf

@@ -126,11 +126,14 @@ int ghf_plan_build(const int64_t* edge_index /* [2,E] row 0 = src, row 1 = dst *
  *  hidden_drop:    training with dropout > 0 (the reference's Linear -> ReLU -> Dropout, weight_generator.py:96-107): the masks,
  *                  already scaled by 1/(1-p), as floats [3 heads][num_hidden][R][Hh] (ghf_weightgen_acts' layout), multiplied
  *                  into every hidden activation; NULL: none.  The caller draws them (the reference draws them with torch's
- *                  generator; so does the Python mirror). */
+ *                  generator; so does the Python mirror).
+ *  acts:           NULL, or where the same launch leaves every hidden layer's output (ghf_weightgen_acts' result and layout:
+ *                  what the backward needs besides the outputs). */
 int ghf_weightgen_fwd(const float* text_emb /* [R,T] */, const float* const* head_params,
                       const float* const* log_scales /* [3] host array of device pointers */, int R, int T, int Hh, int num_hidden,
                       int d_in, int d_out, int layout, float* hidden_ws,
-                      float* W_msg, float* W_self, float* bias, const float* hidden_drop /* or NULL */, void* stream);
+                      float* W_msg, float* W_self, float* bias, const float* hidden_drop /* or NULL */, float* acts /* or NULL */,
+                      void* stream);
 
 /* The L generators of one model (identical shapes: the reference builds one WeightGenerator per layer, hypergnn.py:131-143) in
  * ONE launch sequence — hidden layers, output layers, packing: three kernels for all layers instead of three per layer; on
