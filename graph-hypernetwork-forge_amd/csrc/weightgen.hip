@@ -21,9 +21,9 @@ namespace ghf {
 constexpr int WG_MAX_WIDTH = 1024;   // max(T, Hh) supported by the LDS ping-pong buffers
 constexpr int WG_UNROLL = 8;         // independent dot products per wave and step in the latency-bound small kernels
 #ifndef GHF_WG_HU
-#define GHF_WG_HU 32
+#define GHF_WG_HU 8
 #endif
-constexpr int WG_HU = GHF_WG_HU;     // ... of wg_hidden_kernel: a wave's whole share of a 128-unit layer in one batch of loads
+constexpr int WG_HU = GHF_WG_HU;     // ... of wg_hidden_kernel (32 — a wave's whole share of a 128-unit layer at once — needs 264 registers: one workgroup per CU, 56 -> 130 us at config 3's 576 workgroups; 41 vs 43 us at config 2)
 
 struct HeadPtrs {
     const float* w[3][8];     // [head][layer] weight
@@ -215,6 +215,11 @@ struct OutHeads {
     size_t rstride[3];
 };
 struct OutHeadsL { OutHeads h[WG_MAX_L]; };
+// NJT > 0: Hl = 16 NJT known at compile time — the wave's fragments of W3 are loaded ONCE (they do not depend on the row tile)
+// and a row tile's fragments of z all at once: five round trips per wave instead of one per (row tile, k-step) — the loop
+// below waited for its two loads in every one of its R/16 x Hl/16 iterations (config 3: 77 -> ~20 us).  Same products in the
+// same order: the same bits.
+template <int NJT>
 __global__ __launch_bounds__(256) void wg_out_mfma3_kernel(OutHeadsL HL, int R, int Hl) {
     const int head = blockIdx.y % 3;
     const OutHeads& H = HL.h[blockIdx.y / 3];
@@ -233,6 +238,37 @@ __global__ __launch_bounds__(256) void wg_out_mfma3_kernel(OutHeadsL HL, int R, 
     const float* __restrict__ arow = W3 + (size_t)(a_ok ? n_a : 0) * Hl + 4 * q;
     const float scale = expf(H.log_scale[head][0]);
     const int NJ = Hl >> 4;
+    if constexpr (NJT > 0) {
+        f32x4 a[NJT];
+#pragma unroll
+        for (int j = 0; j < NJT; ++j) {
+            a[j] = *(const f32x4*)(arow + 16 * j);
+            if (!a_ok) a[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int r0 = 0; r0 < R; r0 += 16) {
+            const int rc = r0 + c16;
+            const bool b_ok = rc < R;
+            const float* __restrict__ brow = z + (size_t)(b_ok ? rc : 0) * Hl + 4 * q;
+            f32x4 b[NJT];
+#pragma unroll
+            for (int j = 0; j < NJT; ++j) {
+                b[j] = *(const f32x4*)(brow + 16 * j);
+                if (!b_ok) b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJT; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], b[j][s], acc, 0, 0, 0);
+            if (!b_ok) continue;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = 16 * mt + 4 * q + s;
+                if (n < n_out) out[(size_t)rc * rstride + n] = (acc[s] + b3[n]) * scale;
+            }
+        }
+        return;
+    }
     for (int r0 = 0; r0 < R; r0 += 16) {
         const int rc = r0 + c16;
         const bool b_ok = rc < R;
@@ -458,7 +494,14 @@ int launch_weightgen_batched(int L, const float* text_emb, const float* const* h
         }
     if (merged) {
         const int mtiles = (n_mat + 15) / 16;
-        wg_out_mfma3_kernel<<<dim3((mtiles + 3) / 4, 3 * L), 256, 0, stream>>>(HL, R, Hl);
+        const dim3 og((mtiles + 3) / 4, 3 * L);
+        switch (Hl) {
+            case 32: wg_out_mfma3_kernel<2><<<og, 256, 0, stream>>>(HL, R, Hl); break;
+            case 64: wg_out_mfma3_kernel<4><<<og, 256, 0, stream>>>(HL, R, Hl); break;
+            case 128: wg_out_mfma3_kernel<8><<<og, 256, 0, stream>>>(HL, R, Hl); break;
+            case 256: wg_out_mfma3_kernel<16><<<og, 256, 0, stream>>>(HL, R, Hl); break;
+            default: wg_out_mfma3_kernel<0><<<og, 256, 0, stream>>>(HL, R, Hl); break;
+        }
         GHF_LAUNCH_CHECK();
     } else {
         for (int g = 0; g < L; ++g)
