@@ -196,7 +196,8 @@ constexpr int GHF_BX_AD = 2, GHF_BX_TGB = 3;
 // helpers:   0 barrier wait, 1 DMA issue, 2 fold + table clear, 3 wait for the P1 pieces, 4 descriptor work, 6 epilogue + tail
 #ifdef GHF_STAMPS
 __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
-#define BX_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0
+__device__ unsigned long long ghf_bx_life_buf[8192 * 3];     // per workgroup: first stamp, last stamp, (XCC id << 32) | HW_ID
+#define BX_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_first = 0
 #define BX_STAMP(i)                                                                            \
     do {                                                                                       \
         unsigned long long _t;                                                                 \
@@ -204,12 +205,20 @@ __device__ unsigned long long ghf_bx_stamp_buf[8192 * 8 * 8];
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");             \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         if ((i) >= 0) st_acc[(i) < 0 ? 0 : (i)] += _t - st_last;                               \
+        else st_first = _t;                                                                    \
         st_last = _t;                                                                          \
     } while (0)
 #define BX_STAMP_FLUSH()                                                                       \
     do {                                                                                       \
         if (lane == 0 && blockIdx.x < 8192)                                                    \
             for (int i = 0; i < 8; ++i) ghf_bx_stamp_buf[((size_t)blockIdx.x * 8 + w) * 8 + i] = st_acc[i]; \
+        if (lane == 0 && w == 0 && blockIdx.x < 8192) {  /* the workgroup's life and place: tools/stamps_gap.py */ \
+            unsigned _hw, _xcc;                                                                \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(_hw), "=s"(_xcc)); \
+            ghf_bx_life_buf[(size_t)blockIdx.x * 3] = st_first;                                \
+            ghf_bx_life_buf[(size_t)blockIdx.x * 3 + 1] = st_last;                             \
+            ghf_bx_life_buf[(size_t)blockIdx.x * 3 + 2] = ((unsigned long long)_xcc << 32) | _hw; \
+        }                                                                                      \
     } while (0)
 #else
 #define BX_STAMP_DECL
@@ -1221,5 +1230,8 @@ int launch_message_bx(const MsgArgs& a, hipStream_t stream) {
 #ifdef GHF_STAMPS
 extern "C" int ghf_debug_read_stamps_bx(unsigned long long* host, size_t count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_stamp_buf), count * sizeof(unsigned long long));
+}
+extern "C" int ghf_debug_read_life_bx(unsigned long long* host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ghf::ghf_bx_life_buf), count * sizeof(unsigned long long));
 }
 #endif
