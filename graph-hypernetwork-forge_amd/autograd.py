@@ -49,6 +49,7 @@ class TrainPlan:
     slice_off: Optional[torch.Tensor] = None   # [R+1] int64
     slice_order: Optional[torch.Tensor] = None # [S] int32: the slices in launch order (by position inside their relation)
     ident: Optional[tuple] = None               # (arange(N), slice table, slice offsets): InputProjFn's weight gradient as ghf_edge_outer
+    zero_bias: Optional[torch.Tensor] = None    # [R, d] zeros: the bias operand of the two gradient passes
     carry: Optional["_SplitCarry"] = None       # split rows handed from one layer's launch to the next
 
 SLICE_EDGES = 4096                # edges per ghf_edge_outer workgroup (a multiple of its 32-edge tile)
@@ -239,7 +240,9 @@ class MessageLayerFn(torch.autograd.Function):
             db = _native.group_outer(None, None, G, tp.dst_by_rel, tp.goff).reshape(plan.R, -1)
         dh = None
         if ctx.needs_input_grad[0]:
-            zero_b = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)
+            if tp.zero_bias is None or tp.zero_bias.shape != (plan.R, h.size(1)):      # (one fill per plan, not one per layer and step)
+                tp.zero_bias = torch.zeros(plan.R, h.size(1), dtype=torch.float32, device=h.device)
+            zero_b = tp.zero_bias
             if _ONE_PACK and plan.wlayout == tp.rev.wlayout and plan.wlayout in _native.SPLIT_LAYOUTS:
                 # one packed tensor serves both passes: each declares the half it does not read zero (ZERO_SRC / ZERO_DST)
                 Wf, Wf2 = _layer_weights(plan, W_msg.detach(), W_self.detach(), transpose=True)
